@@ -1,0 +1,74 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of univid_amd.
+// Wave = 64 lanes everywhere; nothing here is portable to 32-wide hardware.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits in HBM
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define UV_WAVE 64
+
+// f32 -> bf16, round-to-nearest-even (same rounding torch's .to(bfloat16) uses).
+// A plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN.
+__device__ __forceinline__ bf16_t f2bf(float x) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) {
+    return __builtin_bit_cast(float, (uint32_t)b << 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+// round an f32 through bf16 and back (the value a bf16 tensor would hold)
+__device__ __forceinline__ float round_bf(float x) { return bf2f(f2bf(x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// GELU(approximate='tanh') evaluated in f32, as torch does for a bf16 tensor
+// (upcast, evaluate, round once): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3))).
+__device__ __forceinline__ float gelu_tanh_f32(float x) {
+    const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
+    const float kKappa = 0.044715f;
+    float inner = kBeta * (x + kKappa * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+__device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
+
+// error plumbing shared by the extern "C" entry points
+extern "C" const char* uv_last_error(void);
+void uv_set_error(const char* fmt, ...);
+
+#define UV_CHECK_ARG(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            uv_set_error(__VA_ARGS__);     \
+            return -1;                     \
+        }                                  \
+    } while (0)
+
+#define UV_CHECK_LAUNCH(name)                                                     \
+    do {                                                                          \
+        hipError_t _e = hipGetLastError();                                        \
+        if (_e != hipSuccess) {                                                   \
+            uv_set_error("%s: launch failed: %s", name, hipGetErrorString(_e));   \
+            return (int)_e;                                                       \
+        }                                                                         \
+    } while (0)

@@ -1,0 +1,421 @@
+// HBM-bound glue kernels of the Wan DiT forward, each a single fused pass (one read + one write of
+// the [L, C] activation), vectorised 16 B/lane, one 64-lane wave per token row.
+//
+// Replaces (reference, all PyTorch eager):
+//   WanLayerNorm + AdaLN modulate   models/wan/utils/modules/model.py:93-98, 239-245, 253, 287-290
+//   WanRMSNorm (QK-norm over dim)   models/wan/utils/modules/model.py:82-85, 138-139, 170-171
+//   rope_apply (complex128 RoPE)    models/wan/utils/modules/model.py:38-66
+//   patch_embedding im2col / unpatchify   model.py:448-451, 499-522
+//   sinusoidal_embedding_1d + time MLPs   model.py:14-24, 384-386, 460-469
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (no affine, eps) over C, then one of:
+//   mode 0: y                                  (plain)
+//   mode 1: y * (1 + scale[t]) + shift[t]      (AdaLN; t = tid[row], rows of a [n_t, tab_stride] table)
+//   mode 2: y * w + b                          (elementwise affine, norm3)
+// `round_ln` rounds y to bf16 first (block 0: the residual stream is still bf16 there, and
+// WanLayerNorm.forward does .type_as(x), model.py:98). Output bf16 or f32.
+// Every product/sum keeps the reference's separate roundings (no FMA contraction).
+// ------------------------------------------------------------------------------------------------
+struct LnArgs {
+    const float* x; long ldx;
+    void* out; long ldo;
+    const float* tab; long tab_stride; int shift_off, scale_off;  // mode 1
+    const int32_t* tid;                                           // mode 1 (nullptr => row 0)
+    const float* w; const float* b;                               // mode 2
+    int L, C; float eps;
+    int mode, round_ln, out_bf16;
+};
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_mod_kernel(LnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.L) return;
+    const int nv = p.C >> 8;  // float4 per lane
+    const float* xr = p.x + (long)row * p.ldx;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+            v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    const float mean = wave_sum(s) / (float)p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    const float var = wave_sum(q) / (float)p.C;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+
+    const float* shift = nullptr;
+    const float* scale = nullptr;
+    if (p.mode == 1) {
+        const int t = p.tid ? p.tid[row] : 0;
+        shift = p.tab + (long)t * p.tab_stride + p.shift_off;
+        scale = p.tab + (long)t * p.tab_stride + p.scale_off;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+            const int c = (i * 64 + lane) * 4;
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = __fmul_rn(v[i][e] - mean, rstd);
+                if (p.round_ln) t = round_bf(t);
+                y[e] = t;
+            }
+            if (p.mode == 1) {
+                const f32x4 sc = *(const f32x4*)(scale + c);
+                const f32x4 sh = *(const f32x4*)(shift + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], __fadd_rn(1.0f, sc[e])), sh[e]);
+            } else if (p.mode == 2) {
+                const f32x4 w = *(const f32x4*)(p.w + c);
+                const f32x4 b = *(const f32x4*)(p.b + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], w[e]), b[e]);
+            }
+            if (p.out_bf16) {
+                u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+                *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;
+            } else {
+                *(f32x4*)((float*)p.out + (long)row * p.ldo + c) = y;
+            }
+        }
+}
+
+extern "C" int uv_layernorm_mod(const float* x, long ldx, void* out, long ldo, int L, int C, float eps,
+                                int mode, const float* tab, long tab_stride, int shift_off, int scale_off,
+                                const int32_t* tid, const float* w, const float* b, int round_ln,
+                                int out_bf16, void* stream) {
+    UV_CHECK_ARG(x && out && L > 0, "uv_layernorm_mod: null pointer / empty");
+    UV_CHECK_ARG(C % 256 == 0 && C <= 8192, "uv_layernorm_mod: C=%d must be a multiple of 256 and <= 8192", C);
+    UV_CHECK_ARG(ldx % 4 == 0 && ldo % 4 == 0, "uv_layernorm_mod: ldx/ldo must be multiples of 4");
+    UV_CHECK_ARG(mode >= 0 && mode <= 2, "uv_layernorm_mod: bad mode %d", mode);
+    if (mode == 1) UV_CHECK_ARG(tab && tab_stride % 4 == 0 && shift_off % 4 == 0 && scale_off % 4 == 0,
+                                "uv_layernorm_mod: modulation table missing / misaligned");
+    if (mode == 2) UV_CHECK_ARG(w && b, "uv_layernorm_mod: affine weight/bias missing");
+    LnArgs a{x, ldx, out, ldo, tab, tab_stride, shift_off, scale_off, tid, w, b, L, C, eps, mode, round_ln, out_bf16};
+    const dim3 grid((L + 3) / 4), block(256);
+    if (C <= 1024) hipLaunchKernelGGL(layernorm_mod_kernel<4>, grid, block, 0, (hipStream_t)stream, a);
+    else if (C <= 4096) hipLaunchKernelGGL(layernorm_mod_kernel<16>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(layernorm_mod_kernel<32>, grid, block, 0, (hipStream_t)stream, a);
+    UV_CHECK_LAUNCH("uv_layernorm_mod");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// QK RMSNorm over the whole projection width C (= heads*head_dim), then optional 3-axis RoPE.
+//   y  = bf16( x * rsqrt(mean(x^2) + eps) )            WanRMSNorm._norm(x.float()).type_as(x)
+//   y  = float(y) * weight                             (fp32 parameter promotes to fp32)
+//   RoPE: pairs (y[2i], y[2i+1]) of every head times freqs[pos][i] in complex128, result -> f32
+//   out = bf16(...)                                    flash_attention's half() cast
+// freqs: [max_pos, D/2] complex128 as (re, im) doubles; the first nf complex columns rotate with the
+// frame index, the next nh with the row index, the last nw with the column index.
+// Rows >= F*Hh*Ww (sequence padding) pass through un-rotated, as rope_apply does (model.py:62).
+// ------------------------------------------------------------------------------------------------
+struct RmsRopeArgs {
+    const bf16_t* x; long ldx;
+    bf16_t* out; long ldo;
+    const float* weight;
+    const double* freqs;  // nullptr => no rope
+    int L, C, D;          // D = head_dim
+    int F, Hh, Ww;        // token grid
+    int nf, nh, nw;       // complex columns per axis
+    float eps;
+};
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsRopeArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.L) return;
+    const int nv = p.C >> 9;                     // 8-element chunks per lane (64 lanes * 8 = 512)
+    const int rem = (p.C & 511) >> 3;            // leftover chunks (C % 512 != 0, e.g. C = 256)
+    const bf16_t* xr = p.x + (long)row * p.ldx;
+    float v[MAXV][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const bool on = (i < nv) || (i == nv && lane < rem);
+        if (on) {
+            const u32x4 raw = *(const u32x4*)(xr + (i * 64 + lane) * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][2 * e] = bf2f((bf16_t)(raw[e] & 0xffff));
+                v[i][2 * e + 1] = bf2f((bf16_t)(raw[e] >> 16));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+        }
+    }
+    const float mean = wave_sum(ss) / (float)p.C;
+    const float rs = 1.0f / sqrtf(mean + p.eps);
+
+    const bool do_rope = p.freqs != nullptr && row < p.F * p.Hh * p.Ww;
+    int pf = 0, ph = 0, pw = 0;
+    if (do_rope) {
+        pw = row % p.Ww;
+        const int t = row / p.Ww;
+        ph = t % p.Hh;
+        pf = t / p.Hh;
+    }
+    const int half = p.D >> 1;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const bool on = (i < nv) || (i == nv && lane < rem);
+        if (on) {
+            const int c0 = (i * 64 + lane) * 8;
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(round_bf(__fmul_rn(v[i][e], rs)), p.weight[c0 + e]);
+            if (do_rope) {
+                const int pair0 = (c0 % p.D) >> 1;  // first complex index of this chunk inside its head
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = pair0 + e;
+                    const int pos = ci < p.nf ? pf : (ci < p.nf + p.nh ? ph : pw);
+                    const double* fr = p.freqs + ((long)pos * half + ci) * 2;
+                    const double cr = fr[0], ci_ = fr[1];
+                    const double a = (double)y[2 * e], b = (double)y[2 * e + 1];
+                    const double re = __dsub_rn(__dmul_rn(a, cr), __dmul_rn(b, ci_));
+                    const double im = __dadd_rn(__dmul_rn(a, ci_), __dmul_rn(b, cr));
+                    y[2 * e] = (float)re;
+                    y[2 * e + 1] = (float)im;
+                }
+            }
+            u32x4 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]), pack_bf2(y[4], y[5]), pack_bf2(y[6], y[7])};
+            *(u32x4*)(p.out + (long)row * p.ldo + c0) = o;
+        }
+    }
+}
+
+extern "C" int uv_rmsnorm_rope(const void* x, long ldx, void* out, long ldo, const float* weight, int L, int C,
+                               int head_dim, float eps, const double* freqs, int F, int Hh, int Ww,
+                               void* stream) {
+    UV_CHECK_ARG(x && out && weight && L > 0, "uv_rmsnorm_rope: null pointer / empty");
+    UV_CHECK_ARG(C % 8 == 0 && C <= 8192, "uv_rmsnorm_rope: C=%d must be a multiple of 8 and <= 8192", C);
+    UV_CHECK_ARG(head_dim % 8 == 0 && C % head_dim == 0, "uv_rmsnorm_rope: bad head_dim %d", head_dim);
+    UV_CHECK_ARG(ldx % 8 == 0 && ldo % 8 == 0, "uv_rmsnorm_rope: ldx/ldo must be multiples of 8");
+    if (freqs) UV_CHECK_ARG(F > 0 && Hh > 0 && Ww > 0 && F <= 1024 && Hh <= 1024 && Ww <= 1024,
+                            "uv_rmsnorm_rope: grid (%d,%d,%d) outside the 1024-row RoPE table", F, Hh, Ww);
+    RmsRopeArgs a;
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.out = (bf16_t*)out; a.ldo = ldo; a.weight = weight; a.freqs = freqs;
+    a.L = L; a.C = C; a.D = head_dim; a.F = F; a.Hh = Hh; a.Ww = Ww; a.eps = eps;
+    const int c = head_dim / 2;  // model.py:43  split [c - 2*(c//3), c//3, c//3]
+    a.nh = c / 3; a.nw = c / 3; a.nf = c - 2 * (c / 3);
+    const dim3 grid((L + 3) / 4), block(256);
+    const int chunks = (C + 511) / 512;
+    if (chunks <= 2) hipLaunchKernelGGL(rmsnorm_rope_kernel<2>, grid, block, 0, (hipStream_t)stream, a);
+    else if (chunks <= 8) hipLaunchKernelGGL(rmsnorm_rope_kernel<8>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(rmsnorm_rope_kernel<16>, grid, block, 0, (hipStream_t)stream, a);
+    UV_CHECK_LAUNCH("uv_rmsnorm_rope");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// patch_embedding im2col: latent [Cin, F, H, W] f32 -> rows [L, Kpad] bf16, column = (c, kt, kh, kw)
+// flattened like Conv3d.weight.flatten(1) (model.py:378-379, 448-451); token = (f', h', w') row-major.
+// Columns >= Cin*pt*ph*pw (K padding to the GEMM's 64 granularity) are zero.
+// ------------------------------------------------------------------------------------------------
+__global__ void patchify_kernel(const float* x, bf16_t* out, long ldo, int Cin, int F, int H, int W,
+                                int pt, int ph, int pw, int Kpad) {
+    const int Fp = F / pt, Hp = H / ph, Wp = W / pw;
+    const long total = (long)Fp * Hp * Wp * Kpad;
+    const int K = Cin * pt * ph * pw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad);
+        const long tok = i / Kpad;
+        float v = 0.f;
+        if (k < K) {
+            const int kw = k % pw, kh = (k / pw) % ph, kt = (k / (pw * ph)) % pt, c = k / (pw * ph * pt);
+            const int wq = (int)(tok % Wp), hq = (int)((tok / Wp) % Hp), fq = (int)(tok / ((long)Wp * Hp));
+            v = x[(((long)c * F + fq * pt + kt) * H + hq * ph + kh) * W + wq * pw + kw];
+        }
+        out[tok * ldo + k] = f2bf(v);
+    }
+}
+
+extern "C" int uv_patchify_bf16(const float* x, void* out, long ldo, int Cin, int F, int H, int W, int pt,
+                                int ph, int pw, int Kpad, void* stream) {
+    UV_CHECK_ARG(x && out, "uv_patchify_bf16: null pointer");
+    UV_CHECK_ARG(pt > 0 && ph > 0 && pw > 0 && F % pt == 0 && H >= ph && W >= pw, "uv_patchify_bf16: bad patch");
+    UV_CHECK_ARG(Kpad >= Cin * pt * ph * pw && ldo >= Kpad, "uv_patchify_bf16: Kpad/ldo too small");
+    const long total = (long)(F / pt) * (H / ph) * (W / pw) * Kpad;
+    const int blocks = (int)min((total + 255) / 256, (long)4096);
+    hipLaunchKernelGGL(patchify_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out, ldo,
+                       Cin, F, H, W, pt, ph, pw, Kpad);
+    UV_CHECK_LAUNCH("uv_patchify_bf16");
+    return 0;
+}
+
+// unpatchify: head output [L, pt*ph*pw*Cout] f32 -> [Cout, Fp*pt, Hp*ph, Wp*pw] f32
+// einsum 'fhwpqrc->cfphqwr' (model.py:518-520): column = ((p*ph + q)*pw + r)*Cout + c
+__global__ void unpatchify_kernel(const float* in, long ldi, float* out, int Cout, int Fp, int Hp, int Wp, int pt,
+                                  int ph, int pw) {
+    const int F = Fp * pt, H = Hp * ph, W = Wp * pw;
+    const long total = (long)Cout * F * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), hh = (int)((i / W) % H), f = (int)((i / ((long)W * H)) % F);
+        const int c = (int)(i / ((long)W * H * F));
+        const int wq = w / pw, r = w % pw, hq = hh / ph, q = hh % ph, fq = f / pt, pp = f % pt;
+        const long tok = ((long)fq * Hp + hq) * Wp + wq;
+        out[i] = in[tok * ldi + ((pp * ph + q) * pw + r) * Cout + c];
+    }
+}
+
+extern "C" int uv_unpatchify_f32(const float* in, long ldi, float* out, int Cout, int Fp, int Hp, int Wp, int pt,
+                                 int ph, int pw, void* stream) {
+    UV_CHECK_ARG(in && out, "uv_unpatchify_f32: null pointer");
+    const long total = (long)Cout * Fp * pt * Hp * ph * Wp * pw;
+    const int blocks = (int)min((total + 255) / 256, (long)4096);
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, ldi, out, Cout, Fp,
+                       Hp, Wp, pt, ph, pw);
+    UV_CHECK_LAUNCH("uv_unpatchify_f32");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sinusoidal_embedding_1d (model.py:14-24): fp64 cos||sin of t * 10000^(-i/half), stored f32.
+// ------------------------------------------------------------------------------------------------
+__global__ void sinusoid_kernel(const float* t, float* out, int n, int dim) {
+    const int half = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * half) return;
+    const int r = i / half, c = i % half;
+    const double freq = pow(10000.0, -((double)c / (double)half));
+    const double a = (double)t[r] * freq;
+    out[(long)r * dim + c] = (float)cos(a);
+    out[(long)r * dim + half + c] = (float)sin(a);
+}
+
+extern "C" int uv_sinusoid_f32(const float* t, float* out, int n, int dim, void* stream) {
+    UV_CHECK_ARG(t && out && n > 0 && dim % 2 == 0, "uv_sinusoid_f32: bad arguments");
+    const int total = n * (dim / 2);
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out, n, dim);
+    UV_CHECK_LAUNCH("uv_sinusoid_f32");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 Linear on a handful of rows (the <=2 distinct timesteps of a forward): out[r][n] =
+// act_in(x[r]) . W[n] + b[n]; one wave per output column, W streamed once (HBM-bound).
+// time_embedding / time_projection  model.py:384-386, 465-468.  act_in: 0 none, 1 SiLU.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float* x, long ldx, const float* W,
+                                                               const float* b, float* out, long ldo, int r0,
+                                                               int N, int K, int act_in) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* wr = W + (long)n * K;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 w = *(const f32x4*)(wr + k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            f32x4 xv = *(const f32x4*)(x + (long)(r0 + r) * ldx + k);
+            if (act_in == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[e] = silu_f32(xv[e]);
+            }
+            acc[r] += xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float s = wave_sum(acc[r]);
+        if (lane == 0) out[(long)(r0 + r) * ldo + n] = s + (b ? b[n] : 0.f);
+    }
+}
+
+extern "C" int uv_linear_rows_f32(const float* x, long ldx, const float* W, const float* b, float* out, long ldo,
+                                  int R, int N, int K, int act_in, void* stream) {
+    UV_CHECK_ARG(x && W && out && R > 0 && N > 0, "uv_linear_rows_f32: bad arguments");
+    UV_CHECK_ARG(K % 4 == 0 && ldx % 4 == 0, "uv_linear_rows_f32: K and ldx must be multiples of 4");
+    const dim3 grid((N + 3) / 4), block(256);
+    int r0 = 0;
+    for (; r0 + 4 <= R; r0 += 4)
+        hipLaunchKernelGGL(linear_rows_f32_kernel<4>, grid, block, 0, (hipStream_t)stream, x, ldx, W, b, out, ldo, r0, N, K, act_in);
+    for (; r0 + 2 <= R; r0 += 2)
+        hipLaunchKernelGGL(linear_rows_f32_kernel<2>, grid, block, 0, (hipStream_t)stream, x, ldx, W, b, out, ldo, r0, N, K, act_in);
+    for (; r0 < R; ++r0)
+        hipLaunchKernelGGL(linear_rows_f32_kernel<1>, grid, block, 0, (hipStream_t)stream, x, ldx, W, b, out, ldo, r0, N, K, act_in);
+    UV_CHECK_LAUNCH("uv_linear_rows_f32");
+    return 0;
+}
+
+// out[r][j][c] = mod[j][c] + e0[r][j][c]   (fp32; (self.modulation.unsqueeze(0) + e) model.py:239, 287)
+__global__ void add_rows_kernel(const float* mod, const float* e0, float* out, int R, long n) {
+    const long total = (long)R * n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        out[i] = __fadd_rn(mod[i % n], e0[i]);
+}
+
+extern "C" int uv_add_rows_f32(const float* mod, const float* e0, float* out, int R, long n, void* stream) {
+    UV_CHECK_ARG(mod && e0 && out && R > 0 && n > 0, "uv_add_rows_f32: bad arguments");
+    const int blocks = (int)min(((long)R * n + 255) / 256, (long)2048);
+    hipLaunchKernelGGL(add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mod, e0, out, R, n);
+    UV_CHECK_LAUNCH("uv_add_rows_f32");
+    return 0;
+}
+
+// f32 -> bf16 cast (weights once, contexts), optional zero row padding handled by the caller's memset
+__global__ void cast_f32_bf16_kernel(const float* in, bf16_t* out, long n) {
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(in + i * 4);
+        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *(u32x2*)(out + i * 4) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = f2bf(in[n4 * 4 + threadIdx.x]);
+}
+
+extern "C" int uv_cast_f32_bf16(const float* in, void* out, long n, void* stream) {
+    UV_CHECK_ARG(in && out && n > 0, "uv_cast_f32_bf16: bad arguments");
+    UV_CHECK_ARG((((uintptr_t)in & 15) | ((uintptr_t)out & 7)) == 0, "uv_cast_f32_bf16: misaligned pointers");
+    const int blocks = (int)min((n / 4 + 255) / 256 + 1, (long)4096);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, n);
+    UV_CHECK_LAUNCH("uv_cast_f32_bf16");
+    return 0;
+}
+
+// x_f32[m][n] += float(y_bf16[m][n])   (un-fused cross-attention residual for the hooked path, model.py:251)
+__global__ void add_bf16_resid_kernel(float* x, long ldx, const bf16_t* y, long ldy, int L, int C) {
+    const int c4 = C >> 2;
+    const long total = (long)L * c4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c4;
+        const int c = (int)(i % c4) * 4;
+        f32x4 xv = *(f32x4*)(x + r * ldx + c);
+        const u32x2 yv = *(const u32x2*)(y + r * ldy + c);
+        xv[0] = __fadd_rn(xv[0], bf2f((bf16_t)(yv[0] & 0xffff)));
+        xv[1] = __fadd_rn(xv[1], bf2f((bf16_t)(yv[0] >> 16)));
+        xv[2] = __fadd_rn(xv[2], bf2f((bf16_t)(yv[1] & 0xffff)));
+        xv[3] = __fadd_rn(xv[3], bf2f((bf16_t)(yv[1] >> 16)));
+        *(f32x4*)(x + r * ldx + c) = xv;
+    }
+}
+
+extern "C" int uv_add_bf16_resid(float* x, long ldx, const void* y, long ldy, int L, int C, void* stream) {
+    UV_CHECK_ARG(x && y && L > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "uv_add_bf16_resid: bad arguments");
+    const int blocks = (int)min(((long)L * (C / 4) + 255) / 256, (long)4096);
+    hipLaunchKernelGGL(add_bf16_resid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (const bf16_t*)y, ldy, L, C);
+    UV_CHECK_LAUNCH("uv_add_bf16_resid");
+    return 0;
+}
