@@ -1,0 +1,109 @@
+/* univid_hip.h - C ABI of libunivid_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary for UniVid's diffusion-decoder hot path. The reference has no native code
+ * and no FFI: its seam is a set of PyTorch op sequences inside
+ * models/wan/utils/modules/{model,attention,vae2_2}.py and models/wan/utils/fm_solvers_unipc.py. Each entry
+ * point below replaces one such sequence (cited per function, paths relative to the reference root) and is what
+ * a ctypes / pybind11 / cffi stub on the reference side would bind (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated; no torch types.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream). Calls are asynchronous on it and never
+ *     synchronise, allocate or free (uv_init() does the one-time allocations), so they can be graph-captured.
+ *   - bf16 tensors are raw uint16 bit patterns; leading dimensions (ld*) are in ELEMENTS.
+ *   - return 0 on success; non-zero on a rejected argument or failed launch, with uv_last_error() describing it.
+ *     Nothing is written on a rejected call. There is no CPU fallback anywhere in this library.
+ */
+#ifndef UNIVID_HIP_H
+#define UNIVID_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ---------------------------------------------------------------------------------------------- */
+int uv_version(void);                      /* 100 = 0.1.0 */
+int uv_init(void);                         /* one-time device allocations; call once per process before use */
+const char* uv_last_error(void);           /* thread-local text of the last failure */
+int uv_device_arch(char* buf, int len);    /* e.g. "gfx950:sramecc+:xnack-" */
+
+/* ---- DiT: GEMMs -------------------------------------------------------------------------------------------- */
+/* epilogue selectors of uv_gemm_bf16_nt */
+#define UV_EPI_BF16 0            /* out_bf16 = bf16(acc + bias)                               nn.Linear under autocast */
+#define UV_EPI_GELU_BF16 1       /* out_bf16 = bf16(gelu_tanh(bf16(acc + bias)))              ffn.0 + GELU, model.py:212-213 */
+#define UV_EPI_F32_FROM_BF16 2   /* out_f32  = float(bf16(acc + bias))                        patch_embedding, model.py:448 */
+#define UV_EPI_RESID_F32 3       /* x_f32   += float(bf16(acc + bias))                        x + cross_attn(...), model.py:251 */
+#define UV_EPI_GATE_RESID_F32 4  /* x_f32    = x + float(bf16(acc + bias)) * gate[tid[m]][n]  x + y*e, model.py:247,255 */
+#define UV_EPI_BF16_T 5          /* outT_bf16[n][m] = bf16(acc + bias)                        V^T for uv_flash_attn_bf16 */
+
+/* C[M,N] = A[M,K] . W[N,K]^T + bias, bf16 operands, fp32 accumulate (MFMA 16x16x32).
+ * Replaces nn.Linear q/k/v/o, ffn.0/ffn.2, text_embedding, patch_embedding (model.py:119-122, 212-214, 378-382).
+ * K % 64 == 0, N % 16 == 0; M arbitrary. bias: bf16 [N] or NULL. gate/gate_tid only for UV_EPI_GATE_RESID_F32
+ * (gate: f32 [n_t, gate_stride]; gate_tid: int32 [M] or NULL = row 0). tile_cfg 0 = auto. */
+int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw, const void* bias_bf16, int M, int N, int K,
+                    int epilogue, void* out, long ldo, const float* gate, const int32_t* gate_tid, long gate_stride,
+                    int tile_cfg, void* stream);
+
+/* C[M,N] = A[M,K] . W[N,K]^T + bias (+ resid), all fp32, exact-f32 MFMA (16x16x4).
+ * Replaces Head.head (fp32 island, model.py:286-290) and the VAE's 1x1 convolutions (vae2_2.py:211,249-250,766-767).
+ * K % 4 == 0, N % 4 == 0. */
+int uv_gemm_f32_nt(const float* A, long lda, const float* W, long ldw, const float* bias, int M, int N, int K, float* out,
+                   long ldo, const float* resid, long ldr, void* stream);
+
+/* ---- DiT: attention ---------------------------------------------------------------------------------------- */
+/* out[Lq, H*D] = softmax(q k^T * softmax_scale) v per head, non-causal, all Lk keys attended.
+ * Replaces flash_attention() (attention.py:24-130) as called at model.py:145-150 and :175.
+ * q [Lq, ldq], k [Lk, ldk] bf16 with head h at columns [h*D, (h+1)*D); vt = V TRANSPOSED, bf16 [H*D, ldvt] with
+ * ldvt >= roundup(Lk, 64) and finite padding; head_dim D in {64, 128}. */
+int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                       int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream);
+
+/* ---- DiT: fused HBM-bound glue ------------------------------------------------------------------------------ */
+/* LayerNorm(no affine) over C then mode 0: y | 1: y*(1+scale[t])+shift[t] (t = tid[row]) | 2: y*w+b.
+ * Replaces WanLayerNorm + AdaLN modulation (model.py:93-98, 239-245, 253, 287-290). round_ln=1 rounds y to bf16 first
+ * (block 0, whose residual stream is still bf16). out is bf16 (out_bf16=1) or f32. C % 256 == 0, C <= 8192. */
+int uv_layernorm_mod(const float* x, long ldx, void* out, long ldo, int L, int C, float eps, int mode, const float* tab,
+                     long tab_stride, int shift_off, int scale_off, const int32_t* tid, const float* w, const float* b,
+                     int round_ln, int out_bf16, void* stream);
+
+/* out = bf16( RoPE( float(bf16(x * rsqrt(mean(x^2)+eps))) * weight ) ); RoPE (complex128 table `freqs`
+ * [1024, head_dim/2] as (re,im) doubles) is skipped when freqs == NULL and for rows >= F*Hh*Ww.
+ * Replaces WanRMSNorm (model.py:82-85) + rope_apply (model.py:38-66) + the bf16 cast of attention.py:59-83. */
+int uv_rmsnorm_rope(const void* x, long ldx, void* out, long ldo, const float* weight, int L, int C, int head_dim,
+                    float eps, const double* freqs, int F, int Hh, int Ww, void* stream);
+
+/* latent [Cin,F,H,W] f32 -> im2col rows [L, Kpad] bf16, column order (c,kt,kh,kw) = Conv3d.weight.flatten(1)
+ * (model.py:378-379, 448-451). */
+int uv_patchify_bf16(const float* x, void* out, long ldo, int Cin, int F, int H, int W, int pt, int ph, int pw, int Kpad,
+                     void* stream);
+/* head rows [L, pt*ph*pw*Cout] f32 -> [Cout, Fp*pt, Hp*ph, Wp*pw] f32 (WanModel.unpatchify, model.py:499-522). */
+int uv_unpatchify_f32(const float* in, long ldi, float* out, int Cout, int Fp, int Hp, int Wp, int pt, int ph, int pw,
+                      void* stream);
+/* sinusoidal_embedding_1d (model.py:14-24): out[n, dim] f32 = cos||sin(t * 10000^(-i/half)) evaluated in fp64. */
+int uv_sinusoid_f32(const float* t, float* out, int n, int dim, void* stream);
+/* out[r][n] = act_in(x[r]) . W[n] + b[n], fp32, for the few distinct timestep rows (time_embedding / time_projection,
+ * model.py:384-386, 465-468). act_in: 0 none, 1 SiLU. */
+int uv_linear_rows_f32(const float* x, long ldx, const float* W, const float* b, float* out, long ldo, int R, int N, int K,
+                       int act_in, void* stream);
+/* out[r][i] = mod[i] + e0[r][i]  (modulation + e, model.py:239, 287) */
+int uv_add_rows_f32(const float* mod, const float* e0, float* out, int R, long n, void* stream);
+int uv_cast_f32_bf16(const float* in, void* out, long n, void* stream);
+/* x_f32 += float(y_bf16): un-fused residual used when WanCrossAttention.forward has been re-assigned (UniVid's hook). */
+int uv_add_bf16_resid(float* x, long ldx, const void* y, long ldy, int L, int C, void* stream);
+
+/* ---- sampler (CFG + flow UniPC order 2 / bh2 / predict-x0) -------------------------------------------------- */
+/* noise_pred = uncond + gs*(cond - uncond) (textimage2video.py:385); x0 = sample - sigma*noise_pred
+ * (fm_solvers_unipc.py:323). noise_pred may be NULL. */
+int uv_cfg_convert(const float* cond, const float* uncond, const float* sample, float guide_scale, float sigma,
+                   float* noise_pred, float* x0, long n, void* stream);
+/* multistep_uni_c_bh_update (fm_solvers_unipc.py:545-628) with host-computed fp32 coefficients. */
+int uv_unipc_corrector(const float* x_last, const float* m0, const float* m_prev, const float* model_t, float* out, float r,
+                       float c1, float c2, float rho0, float rho_last, float rk, int order, long n, void* stream);
+/* multistep_uni_p_bh_update (fm_solvers_unipc.py:397-486). */
+int uv_unipc_predictor(const float* x, const float* m0, const float* m_prev, float* out, float r, float c1, float c2,
+                       float rk, int order, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIVID_HIP_H */

@@ -1,0 +1,161 @@
+"""ctypes binding of libunivid_hip.so (the C ABI declared in include/univid_hip.h).
+
+PyTorch-ROCm tensors in, raw device pointers out: this module is the only place that turns a tensor into
+`data_ptr()` + sizes + the current HIP stream. There is NO fallback: if the shared library is missing or a
+call is rejected, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunivid_hip.so")
+
+_c = ctypes
+_P, _L, _I, _F = _c.c_void_p, _c.c_long, _c.c_int, _c.c_float
+
+# name -> argtypes (all return int unless listed in _RESTYPE)
+SIGNATURES = {
+    "uv_version": [],
+    "uv_init": [],
+    "uv_last_error": [],
+    "uv_device_arch": [_c.c_char_p, _I],
+    "uv_gemm_bf16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
+    "uv_gemm_f32_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _P],
+    "uv_flash_attn_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P],
+    "uv_layernorm_mod": [_P, _L, _P, _L, _I, _I, _F, _I, _P, _L, _I, _I, _P, _P, _P, _I, _I, _P],
+    "uv_rmsnorm_rope": [_P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _I, _I, _I, _P],
+    "uv_patchify_bf16": [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "uv_unpatchify_f32": [_P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "uv_sinusoid_f32": [_P, _P, _I, _I, _P],
+    "uv_linear_rows_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "uv_add_rows_f32": [_P, _P, _P, _I, _L, _P],
+    "uv_cast_f32_bf16": [_P, _P, _L, _P],
+    "uv_add_bf16_resid": [_P, _L, _P, _L, _I, _I, _P],
+    "uv_cfg_convert": [_P, _P, _P, _F, _F, _P, _P, _L, _P],
+    "uv_unipc_corrector": [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _L, _P],
+    "uv_unipc_predictor": [_P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _P],
+}
+_RESTYPE = {"uv_last_error": _c.c_char_p}
+
+EPI_BF16, EPI_GELU_BF16, EPI_F32_FROM_BF16, EPI_RESID_F32, EPI_GATE_RESID_F32, EPI_BF16_T = range(6)
+
+_lib = None
+_inited = False
+
+
+class UnividHipError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Loads the shared library (torch first, so the HIP runtime torch ships is the one both sides use)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise UnividHipError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python -m univid_amd.build`). univid_amd has no CPU/eager fallback.")
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, _I)
+    _lib = lib
+    return lib
+
+
+def init():
+    global _inited
+    lib = load()
+    if not _inited:
+        if not torch.cuda.is_available():
+            raise UnividHipError("no HIP device visible: univid_amd's hot path only runs on an MI355X (gfx950)")
+        torch.cuda.init()
+        rc = lib.uv_init()
+        if rc != 0:
+            raise UnividHipError(f"uv_init failed: {lib.uv_last_error().decode()}")
+        buf = ctypes.create_string_buffer(64)
+        lib.uv_device_arch(buf, 64)
+        arch = buf.value.decode()
+        if not arch.startswith("gfx950"):
+            raise UnividHipError(f"device arch {arch!r} is not gfx950: the kernels are built for MI355X only")
+        _inited = True
+    return lib
+
+
+def stream_ptr():
+    return _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return _c.c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    lib = init()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise UnividHipError(f"{name} failed ({rc}): {lib.uv_last_error().decode()}")
+
+
+# ---- thin typed wrappers (tensor checks live here so the C side only sees valid pointers) -----------------------
+
+def _chk(t, dtype, name):
+    if t.device.type != "cuda":
+        raise UnividHipError(f"{name}: tensor must live on the GPU (got {t.device})")
+    if t.dtype != dtype:
+        raise UnividHipError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise UnividHipError(f"{name}: innermost dimension must be contiguous")
+
+
+def gemm_bf16(a, w, bias, out, epi, M=None, gate=None, gate_tid=None, tile_cfg=0):
+    """a [M,K] bf16, w [N,K] bf16, bias bf16 [N] | None; out per epilogue (see include/univid_hip.h)."""
+    _chk(a, torch.bfloat16, "gemm_bf16.a")
+    _chk(w, torch.bfloat16, "gemm_bf16.w")
+    M = a.shape[0] if M is None else M
+    N, K = w.shape
+    call("uv_gemm_bf16_nt", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), M, N, K, epi, ptr(out), out.stride(0),
+         ptr(gate), ptr(gate_tid), 0 if gate is None else gate.stride(0), tile_cfg, stream_ptr())
+    return out
+
+
+def gemm_f32(a, w, bias, out, resid=None, M=None):
+    _chk(a, torch.float32, "gemm_f32.a")
+    _chk(w, torch.float32, "gemm_f32.w")
+    M = a.shape[0] if M is None else M
+    N, K = w.shape
+    call("uv_gemm_f32_nt", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), M, N, K, ptr(out), out.stride(0),
+         ptr(resid), 0 if resid is None else resid.stride(0), stream_ptr())
+    return out
+
+
+def flash_attn(q, k, vt, out, Lq, Lk, H, D, scale):
+    for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (out, "out")):
+        _chk(t, torch.bfloat16, "flash_attn." + n)
+    call("uv_flash_attn_bf16", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(vt), vt.stride(0), ptr(out), out.stride(0),
+         Lq, Lk, H, D, float(scale), stream_ptr())
+    return out
+
+
+def layernorm_mod(x, out, L, C, eps, mode=0, tab=None, shift_off=0, scale_off=0, tid=None, w=None, b=None,
+                  round_ln=False):
+    _chk(x, torch.float32, "layernorm_mod.x")
+    call("uv_layernorm_mod", ptr(x), x.stride(0), ptr(out), out.stride(0), L, C, float(eps), mode, ptr(tab),
+         0 if tab is None else tab.stride(0), shift_off, scale_off, ptr(tid), ptr(w), ptr(b), int(round_ln),
+         int(out.dtype == torch.bfloat16), stream_ptr())
+    return out
+
+
+def rmsnorm_rope(x, out, weight, L, C, D, eps, freqs=None, grid=(0, 0, 0)):
+    _chk(x, torch.bfloat16, "rmsnorm_rope.x")
+    _chk(out, torch.bfloat16, "rmsnorm_rope.out")
+    call("uv_rmsnorm_rope", ptr(x), x.stride(0), ptr(out), out.stride(0), ptr(weight), L, C, D, float(eps), ptr(freqs),
+         int(grid[0]), int(grid[1]), int(grid[2]), stream_ptr())
+    return out

@@ -1,0 +1,479 @@
+"""Wan DiT (`WanModel`) on MI355X: the reference's module tree / parameter names / call signatures over the
+hand-written HIP kernels of libunivid_hip.so.
+
+Mirrors /root/reference/models/wan/utils/modules/model.py (WanModel :294-546, WanAttentionBlock :183-259,
+WanSelfAttention :101-155, WanCrossAttention :158-180, Head :262-291, WanRMSNorm :69-85, WanLayerNorm :88-98)
+so that UniVid's own code keeps working against it: `.blocks` is an nn.ModuleList, cross-attention modules are
+instances of a class NAMED `WanCrossAttention` whose `.forward(x, context, context_lens)` can be re-assigned
+per instance (models/model_pipeline.py:1745-1807), the nn.Linear children are called
+self_attn.{q,k,v,o} / cross_attn.{q,k,v,o} / ffn.0 / ffn.2 (LoRA targets, model_pipeline.py:474-493), and the
+state-dict keys equal the reference's, so its checkpoints load.
+
+Numerics contract = UniVid's runtime setting (fp32 parameters, ambient autocast(bf16), fp32 islands; SURVEY.md
+Appendix A): parameters stay fp32 nn.Parameters; `prepare()` makes the bf16 copies autocast would make on
+every call. Every op runs in a HIP kernel; torch is used for memory, streams and views only. There is no
+eager fallback: without the extension or a gfx950 device, forward raises.
+
+Per-token timesteps (`t` of shape [B, seq_len], textimage2video.py:373-378) are handled without materialising
+the reference's [L, 6, dim] fp32 modulation tensor (843 MB at L = 11 440): the distinct timestep values
+(1 for t2v, 2 for i2v) go through the time MLPs once, and kernels index the resulting rows with a
+token -> row map.
+"""
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import (EPI_BF16, EPI_BF16_T, EPI_F32_FROM_BF16, EPI_GATE_RESID_F32, EPI_GELU_BF16, EPI_RESID_F32)
+
+__all__ = ["WanModel"]
+
+BF16 = torch.bfloat16
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def rope_params(max_seq_len, dim, theta=10000):
+    """complex128 phasor table (model.py:27-35); built once on the host in fp64."""
+    ang = torch.outer(torch.arange(max_seq_len),
+                      1.0 / torch.pow(theta, torch.arange(0, dim, 2).to(torch.float64).div(dim)))
+    return torch.polar(torch.ones_like(ang), ang)
+
+
+class _Prepared:
+    """bf16 weight/bias copies of one nn.Linear (what autocast's weight cache holds in the reference)."""
+    __slots__ = ("w", "b")
+
+    def __init__(self, lin: nn.Linear, pad_k: int = 0):
+        w = lin.weight.detach()
+        if pad_k and w.shape[1] % pad_k:
+            w = torch.nn.functional.pad(w, (0, pad_k - w.shape[1] % pad_k))
+        self.w = w.to(BF16).contiguous()
+        self.b = None if lin.bias is None else lin.bias.detach().to(BF16).contiguous()
+
+
+class WanRMSNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+
+class WanLayerNorm(nn.LayerNorm):
+    def __init__(self, dim, eps=1e-6, elementwise_affine=False):
+        super().__init__(dim, elementwise_affine=elementwise_affine, eps=eps)
+
+
+class WanSelfAttention(nn.Module):
+    def __init__(self, dim, num_heads, window_size=(-1, -1), qk_norm=True, eps=1e-6):
+        assert dim % num_heads == 0
+        super().__init__()
+        self.dim, self.num_heads, self.head_dim = dim, num_heads, dim // num_heads
+        self.window_size, self.qk_norm, self.eps = window_size, qk_norm, eps
+        if tuple(window_size) != (-1, -1) or not qk_norm:
+            raise NotImplementedError("only the TI2V-5B setting (global attention, qk_norm) is built")
+        self.q = nn.Linear(dim, dim)
+        self.k = nn.Linear(dim, dim)
+        self.v = nn.Linear(dim, dim)
+        self.o = nn.Linear(dim, dim)
+        self.norm_q = WanRMSNorm(dim, eps=eps)
+        self.norm_k = WanRMSNorm(dim, eps=eps)
+        self._prep = None
+
+    def prepare(self):
+        self._prep = {n: _Prepared(getattr(self, n)) for n in ("q", "k", "v", "o")}
+
+    def _self_attn(self, h, L, grid, freqs, x_resid, gate, gate_tid):
+        """h: bf16 [L, C] modulated input. Adds o(attn) * gate into x_resid (fp32) in the GEMM epilogue."""
+        C, H, D = self.dim, self.num_heads, self.head_dim
+        p = self._prep
+        dev = h.device
+        ql = torch.empty(L, C, dtype=BF16, device=dev)
+        kl = torch.empty(L, C, dtype=BF16, device=dev)
+        vt = _zeros_cached(("vt", C, _round_up(L, 64), dev), (C, _round_up(L, 64)), BF16, dev)
+        _lib.gemm_bf16(h, p["q"].w, p["q"].b, ql, EPI_BF16, M=L)
+        _lib.gemm_bf16(h, p["k"].w, p["k"].b, kl, EPI_BF16, M=L)
+        _lib.gemm_bf16(h, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=L)
+        _lib.rmsnorm_rope(ql, ql, self.norm_q.weight, L, C, D, self.eps, freqs, grid)
+        _lib.rmsnorm_rope(kl, kl, self.norm_k.weight, L, C, D, self.eps, freqs, grid)
+        att = torch.empty(L, C, dtype=BF16, device=dev)
+        _lib.flash_attn(ql, kl, vt, att, L, L, H, D, 1.0 / math.sqrt(D))
+        _lib.gemm_bf16(att, p["o"].w, p["o"].b, x_resid, EPI_GATE_RESID_F32, M=L, gate=gate, gate_tid=gate_tid)
+
+    def forward(self, x, seq_lens, grid_sizes, freqs):
+        """Reference signature (model.py:126-155): x [B, L, C] -> [B, L, C] bf16. Keys >= seq_lens[b] are masked,
+        which here means: only the first seq_lens[b] tokens are attended (the rest of L is padding)."""
+        _ensure_prepared(self)
+        outs = []
+        fr = _freqs_device(freqs, x.device)
+        for b in range(x.size(0)):
+            L = x.size(1)
+            Lk = int(seq_lens[b])
+            h = x[b].to(BF16).contiguous()
+            C, H, D = self.dim, self.num_heads, self.head_dim
+            p = self._prep
+            ql = torch.empty(L, C, dtype=BF16, device=x.device)
+            kl = torch.empty(L, C, dtype=BF16, device=x.device)
+            vt = torch.zeros(C, _round_up(L, 64), dtype=BF16, device=x.device)
+            _lib.gemm_bf16(h, p["q"].w, p["q"].b, ql, EPI_BF16)
+            _lib.gemm_bf16(h, p["k"].w, p["k"].b, kl, EPI_BF16)
+            _lib.gemm_bf16(h, p["v"].w, p["v"].b, vt, EPI_BF16_T)
+            grid = tuple(int(v) for v in grid_sizes[b])
+            _lib.rmsnorm_rope(ql, ql, self.norm_q.weight, L, C, D, self.eps, fr, grid)
+            _lib.rmsnorm_rope(kl, kl, self.norm_k.weight, L, C, D, self.eps, fr, grid)
+            att = torch.empty(L, C, dtype=BF16, device=x.device)
+            _lib.flash_attn(ql, kl, vt, att, L, Lk, H, D, 1.0 / math.sqrt(D))
+            y = torch.empty(L, C, dtype=BF16, device=x.device)
+            _lib.gemm_bf16(att, p["o"].w, p["o"].b, y, EPI_BF16)
+            outs.append(y)
+        return torch.stack(outs)
+
+
+class WanCrossAttention(WanSelfAttention):
+    """Text cross-attention (model.py:158-180). The class name and the (x, context, context_lens) signature are
+    part of UniVid's contract: Wan22ContextWrapper finds modules by `__class__.__name__ == 'WanCrossAttention'`
+    and replaces `module.forward` with a closure that rescales `context` (model_pipeline.py:1745-1807)."""
+
+    def _attend(self, hq, ctx, L, Lc):
+        """hq bf16 [L, C] (normed queries' input), ctx bf16 [Lc, C] -> attention output bf16 [L, C] (pre-o)."""
+        C, H, D = self.dim, self.num_heads, self.head_dim
+        p = self._prep
+        dev = hq.device
+        ql = torch.empty(L, C, dtype=BF16, device=dev)
+        kl = torch.empty(Lc, C, dtype=BF16, device=dev)
+        vt = _zeros_cached(("cvt", C, _round_up(Lc, 64), dev), (C, _round_up(Lc, 64)), BF16, dev)
+        _lib.gemm_bf16(hq, p["q"].w, p["q"].b, ql, EPI_BF16, M=L)
+        _lib.gemm_bf16(ctx, p["k"].w, p["k"].b, kl, EPI_BF16, M=Lc)
+        _lib.gemm_bf16(ctx, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=Lc)
+        _lib.rmsnorm_rope(ql, ql, self.norm_q.weight, L, C, D, self.eps)
+        _lib.rmsnorm_rope(kl, kl, self.norm_k.weight, Lc, C, D, self.eps)
+        att = torch.empty(L, C, dtype=BF16, device=dev)
+        _lib.flash_attn(ql, kl, vt, att, L, Lc, H, D, 1.0 / math.sqrt(D))
+        return att
+
+    def _cross_fused(self, hq, ctx, L, Lc, x_resid):
+        att = self._attend(hq, ctx, L, Lc)
+        p = self._prep["o"]
+        _lib.gemm_bf16(att, p.w, p.b, x_resid, EPI_RESID_F32, M=L)
+
+    def forward(self, x, context, context_lens=None):
+        """x [B, L1, C], context [B, L2, C] -> [B, L1, C] bf16 (the caller adds it to the residual stream)."""
+        if context_lens is not None:
+            raise NotImplementedError("context_lens is always None on UniVid's path (model.py:472)")
+        _ensure_prepared(self)
+        outs = []
+        for b in range(x.size(0)):
+            L, Lc = x.size(1), context.size(1)
+            att = self._attend(x[b].to(BF16).contiguous(), context[b].to(BF16).contiguous(), L, Lc)
+            y = torch.empty(L, self.dim, dtype=BF16, device=x.device)
+            p = self._prep["o"]
+            _lib.gemm_bf16(att, p.w, p.b, y, EPI_BF16)
+            outs.append(y)
+        return torch.stack(outs)
+
+
+class WanAttentionBlock(nn.Module):
+    def __init__(self, dim, ffn_dim, num_heads, window_size=(-1, -1), qk_norm=True, cross_attn_norm=False, eps=1e-6):
+        super().__init__()
+        self.dim, self.ffn_dim, self.num_heads, self.eps = dim, ffn_dim, num_heads, eps
+        self.window_size, self.qk_norm, self.cross_attn_norm = window_size, qk_norm, cross_attn_norm
+        self.norm1 = WanLayerNorm(dim, eps)
+        self.self_attn = WanSelfAttention(dim, num_heads, window_size, qk_norm, eps)
+        self.norm3 = WanLayerNorm(dim, eps, elementwise_affine=True) if cross_attn_norm else nn.Identity()
+        self.cross_attn = WanCrossAttention(dim, num_heads, (-1, -1), qk_norm, eps)
+        self.norm2 = WanLayerNorm(dim, eps)
+        self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
+        self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
+        self._prep = None
+
+    def prepare(self):
+        self.self_attn.prepare()
+        self.cross_attn.prepare()
+        self._prep = {"ffn0": _Prepared(self.ffn[0]), "ffn2": _Prepared(self.ffn[2])}
+
+    def _run(self, x, L, e0_rows, tid, grid, freqs, ctx, first_block):
+        """x: fp32 [L, C] residual stream, updated IN PLACE. e0_rows: fp32 [n_t, 6C]; tid int32 [L] | None;
+        ctx: bf16 [Lc, C] embedded context."""
+        C = self.dim
+        dev = x.device
+        n_t = e0_rows.shape[0]
+        tab = torch.empty(n_t, 6 * C, dtype=torch.float32, device=dev)
+        _lib.call("uv_add_rows_f32", _lib.ptr(self.modulation), _lib.ptr(e0_rows), _lib.ptr(tab), n_t, 6 * C,
+                  _lib.stream_ptr())                                                               # model.py:239
+        h = torch.empty(L, C, dtype=BF16, device=dev)
+        # self-attention (model.py:243-247)
+        _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=0, scale_off=C, tid=tid,
+                           round_ln=first_block)
+        self.self_attn._self_attn(h, L, grid, freqs, x, tab[:, 2 * C:], tid)
+        # cross-attention (model.py:251)
+        if self.cross_attn_norm:
+            _lib.layernorm_mod(x, h, L, C, self.eps, mode=2, w=self.norm3.weight, b=self.norm3.bias)
+        else:
+            _lib.call("uv_cast_f32_bf16", _lib.ptr(x), _lib.ptr(h), L * C, _lib.stream_ptr())
+        if "forward" in self.cross_attn.__dict__:
+            # forward was re-assigned on the instance (UniVid hook): honour it, then add the residual un-fused
+            y = self.cross_attn.forward(h[:L].unsqueeze(0), ctx.unsqueeze(0), None)
+            y = y[0].contiguous()
+            _lib.call("uv_add_bf16_resid", _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), L, C, _lib.stream_ptr())
+        else:
+            self.cross_attn._cross_fused(h, ctx, L, ctx.shape[0], x)
+        # FFN (model.py:252-255)
+        _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=3 * C, scale_off=4 * C, tid=tid)
+        mid = torch.empty(L, self.ffn_dim, dtype=BF16, device=dev)
+        _lib.gemm_bf16(h, self._prep["ffn0"].w, self._prep["ffn0"].b, mid, EPI_GELU_BF16, M=L)
+        _lib.gemm_bf16(mid, self._prep["ffn2"].w, self._prep["ffn2"].b, x, EPI_GATE_RESID_F32, M=L,
+                       gate=tab[:, 5 * C:], gate_tid=tid)
+
+    def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens=None):
+        """Reference signature (model.py:219-259): x [B, L, C], e [B, L, 6, C] fp32 -> [B, L, C] fp32.
+        Every token carries its own modulation row here (the general case the reference materialises)."""
+        assert e.dtype == torch.float32
+        _ensure_prepared(self)
+        fr = _freqs_device(freqs, x.device)
+        outs = []
+        for b in range(x.size(0)):
+            L = x.size(1)
+            if int(seq_lens[b]) != L:
+                raise NotImplementedError("padded sequences: call WanModel.forward, which strips the padding")
+            xb = x[b].float().contiguous().clone()
+            tid = torch.arange(L, dtype=torch.int32, device=x.device)
+            self._run(xb, L, e[b].reshape(L, -1).contiguous(), tid, tuple(int(v) for v in grid_sizes[b]), fr,
+                      context[b].to(BF16).contiguous(), first_block=(x.dtype == BF16))
+            outs.append(xb)
+        return torch.stack(outs)
+
+
+class Head(nn.Module):
+    def __init__(self, dim, out_dim, patch_size, eps=1e-6):
+        super().__init__()
+        self.dim, self.out_dim, self.patch_size, self.eps = dim, out_dim, patch_size, eps
+        self.norm = WanLayerNorm(dim, eps)
+        self.head = nn.Linear(dim, math.prod(patch_size) * out_dim)
+        self.modulation = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
+
+    def _run(self, x, L, e_rows, tid):
+        """fp32 island (model.py:286-290): LN -> modulate -> Linear, all fp32. Returns [L, P*Cout] fp32."""
+        C = self.dim
+        dev = x.device
+        n_t = e_rows.shape[0]
+        tab = torch.empty(n_t, 2 * C, dtype=torch.float32, device=dev)
+        e2 = e_rows.repeat(1, 2).contiguous()       # e.unsqueeze(2) broadcast over the 2 modulation rows
+        _lib.call("uv_add_rows_f32", _lib.ptr(self.modulation), _lib.ptr(e2), _lib.ptr(tab), n_t, 2 * C, _lib.stream_ptr())
+        hh = torch.empty(L, C, dtype=torch.float32, device=dev)
+        _lib.layernorm_mod(x, hh, L, C, self.eps, mode=1, tab=tab, shift_off=0, scale_off=C, tid=tid)
+        out = torch.empty(L, self.head.out_features, dtype=torch.float32, device=dev)
+        _lib.gemm_f32(hh, self.head.weight, self.head.bias, out, M=L)
+        return out
+
+
+_zero_cache = {}
+
+
+def _zeros_cached(key, shape, dtype, device):
+    """Zero-initialised scratch whose padding region is never written (V^T column padding)."""
+    t = _zero_cache.get(key)
+    if t is None:
+        t = torch.zeros(shape, dtype=dtype, device=device)
+        _zero_cache[key] = t
+    return t
+
+
+def _ensure_prepared(mod):
+    if getattr(mod, "_prep", None) is None:
+        mod.prepare()
+
+
+def _freqs_device(freqs, device):
+    """complex128 [1024, D/2] -> float64 [1024, D/2, 2] on the device (cached on the tensor object)."""
+    cached = getattr(freqs, "_uv_dev", None)
+    if cached is not None and cached.device == device:
+        return cached
+    fr = torch.view_as_real(freqs.to(torch.complex128)).contiguous().to(device)
+    try:
+        freqs._uv_dev = fr
+    except Exception:
+        pass
+    return fr
+
+
+class WanModel(nn.Module):
+    """Wan diffusion backbone (reference WanModel, model.py:294-546), HIP-backed."""
+
+    def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
+                 freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, window_size=(-1, -1), qk_norm=True,
+                 cross_attn_norm=True, eps=1e-6):
+        super().__init__()
+        assert model_type in ["t2v", "i2v", "ti2v", "s2v"]
+        self.model_type = model_type
+        self.patch_size = tuple(patch_size)
+        self.text_len, self.in_dim, self.dim, self.ffn_dim = text_len, in_dim, dim, ffn_dim
+        self.freq_dim, self.text_dim, self.out_dim = freq_dim, text_dim, out_dim
+        self.num_heads, self.num_layers = num_heads, num_layers
+        self.window_size, self.qk_norm, self.cross_attn_norm, self.eps = window_size, qk_norm, cross_attn_norm, eps
+        self.config = dict(model_type=model_type, patch_size=self.patch_size, text_len=text_len, in_dim=in_dim, dim=dim,
+                           ffn_dim=ffn_dim, freq_dim=freq_dim, text_dim=text_dim, out_dim=out_dim, num_heads=num_heads,
+                           num_layers=num_layers, window_size=window_size, qk_norm=qk_norm,
+                           cross_attn_norm=cross_attn_norm, eps=eps)
+
+        self.patch_embedding = nn.Conv3d(in_dim, dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim), nn.GELU(approximate="tanh"), nn.Linear(dim, dim))
+        self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
+        self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6))
+        self.blocks = nn.ModuleList([
+            WanAttentionBlock(dim, ffn_dim, num_heads, window_size, qk_norm, cross_attn_norm, eps)
+            for _ in range(num_layers)
+        ])
+        self.head = Head(dim, out_dim, self.patch_size, eps)
+
+        assert (dim % num_heads) == 0 and (dim // num_heads) % 2 == 0
+        d = dim // num_heads
+        if d not in (64, 128):
+            raise NotImplementedError(f"head_dim {d}: the attention kernel is built for 64 and 128")
+        # plain attribute like the reference (model.py:397-405), so .to() does not change its dtype
+        self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
+                                rope_params(1024, 2 * (d // 6))], dim=1)
+        self._prep = None
+        self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
+
+    # ---- weight preparation -------------------------------------------------------------------------------
+    def invalidate(self):
+        """Forget the bf16 weight copies (call after changing parameters in place)."""
+        self._prep = None
+        for b in self.blocks:
+            b._prep = None
+            b.self_attn._prep = None
+            b.cross_attn._prep = None
+
+    def prepare(self):
+        """Materialise the bf16 operand copies autocast would create on every call of the reference."""
+        dev = self.patch_embedding.weight.device
+        if dev.type != "cuda":
+            raise _lib.UnividHipError("WanModel.prepare: parameters must be on the GPU (model.to('cuda')) - there is "
+                                      "no CPU path in univid_amd")
+        _lib.init()
+        pe = nn.Linear(1, 1, bias=True)
+        pe.weight = nn.Parameter(self.patch_embedding.weight.detach().flatten(1), requires_grad=False)
+        pe.bias = nn.Parameter(self.patch_embedding.bias.detach(), requires_grad=False)
+        self._prep = {
+            "patch": _Prepared(pe, pad_k=64),
+            "text0": _Prepared(self.text_embedding[0], pad_k=64),
+            "text2": _Prepared(self.text_embedding[2]),
+        }
+        for b in self.blocks:
+            b.prepare()
+        return self
+
+    # ---- pieces of forward --------------------------------------------------------------------------------
+    def _time_rows(self, tvals):
+        """tvals: fp32 [n_t] distinct timesteps -> (e [n_t, C], e0 [n_t, 6C]) fp32 (model.py:462-469)."""
+        n_t = tvals.numel()
+        dev = tvals.device
+        C = self.dim
+        sp = _lib.stream_ptr()
+        emb = torch.empty(n_t, self.freq_dim, dtype=torch.float32, device=dev)
+        _lib.call("uv_sinusoid_f32", _lib.ptr(tvals), _lib.ptr(emb), n_t, self.freq_dim, sp)
+        te0, te2, tp = self.time_embedding[0], self.time_embedding[2], self.time_projection[1]
+        h1 = torch.empty(n_t, C, dtype=torch.float32, device=dev)
+        e = torch.empty(n_t, C, dtype=torch.float32, device=dev)
+        e0 = torch.empty(n_t, 6 * C, dtype=torch.float32, device=dev)
+        _lib.call("uv_linear_rows_f32", _lib.ptr(emb), emb.stride(0), _lib.ptr(te0.weight), _lib.ptr(te0.bias), _lib.ptr(h1),
+                  h1.stride(0), n_t, C, self.freq_dim, 0, sp)
+        _lib.call("uv_linear_rows_f32", _lib.ptr(h1), h1.stride(0), _lib.ptr(te2.weight), _lib.ptr(te2.bias), _lib.ptr(e),
+                  e.stride(0), n_t, C, C, 1, sp)
+        _lib.call("uv_linear_rows_f32", _lib.ptr(e), e.stride(0), _lib.ptr(tp.weight), _lib.ptr(tp.bias), _lib.ptr(e0),
+                  e0.stride(0), n_t, 6 * C, C, 1, sp)
+        return e, e0
+
+    def embed_context(self, context: List[torch.Tensor]):
+        """text_embedding on the zero-padded prompt embeddings (model.py:472-478) -> bf16 [B, text_len, C]."""
+        _ensure_prepared(self)
+        dev = self.patch_embedding.weight.device
+        Kp = self._prep["text0"].w.shape[1]
+        outs = []
+        for u in context:
+            if u.size(0) > self.text_len:
+                raise ValueError(f"context has {u.size(0)} rows > text_len {self.text_len}")
+            a = torch.zeros(self.text_len, Kp, dtype=BF16, device=dev)
+            a[:u.size(0), :u.size(1)] = u.to(device=dev, dtype=BF16)
+            h = torch.empty(self.text_len, self.dim, dtype=BF16, device=dev)
+            _lib.gemm_bf16(a, self._prep["text0"].w, self._prep["text0"].b, h, EPI_GELU_BF16)
+            c = torch.empty(self.text_len, self.dim, dtype=BF16, device=dev)
+            _lib.gemm_bf16(h, self._prep["text2"].w, self._prep["text2"].b, c, EPI_BF16)
+            outs.append(c)
+        return torch.stack(outs)
+
+    def forward(self, x, t, context, seq_len, y=None):
+        r"""Same contract as the reference (model.py:410-497).
+
+        x: List[Tensor[C_in, F, H, W]] fp32; t: Tensor[B] or Tensor[B, seq_len]; context: List[Tensor[L<=text_len,
+        text_dim]]; seq_len: int. Returns List[Tensor[C_out, F, H, W]] float32.
+        """
+        if self.model_type == "i2v":
+            assert y is not None
+        _ensure_prepared(self)
+        dev = self.patch_embedding.weight.device
+        if y is not None:
+            x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]
+        if t.dim() == 1:  # one timestep per sample (model.py:460-461)
+            t = t.view(-1, 1).expand(-1, seq_len)
+        ctx_all = self.embed_context(context)
+        fr = _freqs_device(self.freqs, dev)
+        pt, ph, pw = self.patch_size
+        C = self.dim
+        sp = _lib.stream_ptr
+        outs = []
+        for b, u in enumerate(x):
+            u = u.to(device=dev, dtype=torch.float32).contiguous()
+            cin, F, H, W = u.shape
+            Fp, Hp, Wp = F // pt, H // ph, W // pw
+            L = Fp * Hp * Wp
+            assert L <= seq_len, "sequence longer than seq_len (model.py:453)"
+            # patch embedding: im2col -> GEMM, bf16 result stored as the fp32 residual stream (model.py:448-451)
+            Kp = self._prep["patch"].w.shape[1]
+            a = torch.empty(L, Kp, dtype=BF16, device=dev)
+            _lib.call("uv_patchify_bf16", _lib.ptr(u), _lib.ptr(a), a.stride(0), cin, F, H, W, pt, ph, pw, Kp, sp())
+            xs = torch.empty(L, C, dtype=torch.float32, device=dev)
+            _lib.gemm_bf16(a, self._prep["patch"].w, self._prep["patch"].b, xs, EPI_F32_FROM_BF16)
+            # timesteps: distinct values -> rows; token -> row map (padding tokens beyond L are never computed)
+            tb = t[b].to(device=dev, dtype=torch.float32).flatten()[:L]
+            tvals, inv = torch.unique(tb, return_inverse=True)
+            tid = None if tvals.numel() == 1 else inv.to(torch.int32).contiguous()
+            e_rows, e0_rows = self._time_rows(tvals.contiguous())
+            ctx = ctx_all[b]
+            for i, blk in enumerate(self.blocks):
+                blk._run(xs, L, e0_rows, tid, (Fp, Hp, Wp), fr, ctx, first_block=(i == 0))
+            yh = self.head._run(xs, L, e_rows, tid)
+            out = torch.empty(self.out_dim, Fp * pt, Hp * ph, Wp * pw, dtype=torch.float32, device=dev)
+            _lib.call("uv_unpatchify_f32", _lib.ptr(yh), yh.stride(0), _lib.ptr(out), self.out_dim, Fp, Hp, Wp, pt, ph, pw,
+                      sp())
+            outs.append(out)
+        return outs
+
+    def unpatchify(self, x, grid_sizes):
+        """model.py:499-522, for callers that use it directly."""
+        outs = []
+        pt, ph, pw = self.patch_size
+        for u, v in zip(x, grid_sizes.tolist()):
+            u = u[:math.prod(v)].float().contiguous()
+            out = torch.empty(self.out_dim, v[0] * pt, v[1] * ph, v[2] * pw, dtype=torch.float32, device=u.device)
+            _lib.call("uv_unpatchify_f32", _lib.ptr(u), u.stride(0), _lib.ptr(out), self.out_dim, v[0], v[1], v[2], pt, ph,
+                      pw, _lib.stream_ptr())
+            outs.append(out)
+        return outs
+
+    def init_weights(self, seed=0):
+        """Deterministic synthetic init (there are no checkpoints offline); see univid_amd.detinit."""
+        from .. import detinit
+        detinit.init_module_(self, seed)
+        self.invalidate()
+        return self
+
+    @classmethod
+    def from_config(cls, cfg: dict):
+        keys = ("model_type", "patch_size", "text_len", "in_dim", "dim", "ffn_dim", "freq_dim", "text_dim", "out_dim",
+                "num_heads", "num_layers", "window_size", "qk_norm", "cross_attn_norm", "eps")
+        return cls(**{k: cfg[k] for k in keys if k in cfg})

@@ -1,0 +1,239 @@
+"""WanTI2V on MI355X: the denoise loop (2 DiT forwards + CFG + UniPC per step) and VAE decode/encode.
+
+Mirrors /root/reference/models/wan/textimage2video.py (WanTI2V :34-619; generate :162-237, t2v :239-411,
+i2v :413-619) with the same method names, keyword arguments and defaults. Differences that are deliberate:
+
+  * the text encoder is injected (`text_encoder(list_of_prompts, device) -> list[Tensor[len, text_dim]]`); the
+    umT5-XXL encoder produces the prompt-embeds that this hot path takes as INPUT and is outside its scope
+    (SURVEY.md section 8, row #8). `prompt_embeds=` / `negative_prompt_embeds=` can be passed directly.
+  * the device is an argument instead of the hard-coded `cuda:{id}`; offload_model is accepted and ignored
+    (288 GB HBM: nothing is ever moved to the host).
+  * generation errors raise instead of being swallowed.
+"""
+import math
+import random
+import sys
+from typing import Callable, List, Optional
+
+import torch
+
+from .fm_solvers_unipc import FlowUniPCMultistepScheduler
+from .model import WanModel
+
+
+def masks_like(tensor, zero=False, generator=None, p=0.2):
+    """models/wan/utils/utils.py:172-199."""
+    assert isinstance(tensor, list)
+    out1 = [torch.ones(u.shape, dtype=u.dtype, device=u.device) for u in tensor]
+    out2 = [torch.ones(u.shape, dtype=u.dtype, device=u.device) for u in tensor]
+    if zero:
+        if generator is not None:
+            for u, v in zip(out1, out2):
+                random_num = torch.rand(1, generator=generator, device=generator.device).item()
+                if random_num < p:
+                    u[:, 0] = torch.normal(mean=-3.5, std=0.5, size=(1,), device=u.device,
+                                           generator=generator).expand_as(u[:, 0]).exp()
+                    v[:, 0] = torch.zeros_like(v[:, 0])
+        else:
+            for u, v in zip(out1, out2):
+                u[:, 0] = torch.zeros_like(u[:, 0])
+                v[:, 0] = torch.zeros_like(v[:, 0])
+    return out1, out2
+
+
+def best_output_size(w, h, dw, dh, expected_area):
+    """models/wan/utils/utils.py:202-225."""
+    ratio = w / h
+    ow = (expected_area * ratio) ** 0.5
+    oh = expected_area / ow
+    ow1 = int(ow // dw * dw)
+    oh1 = int(expected_area / ow1 // dh * dh)
+    assert ow1 % dw == 0 and oh1 % dh == 0 and ow1 * oh1 <= expected_area
+    ratio1 = ow1 / oh1
+    oh2 = int(oh // dh * dh)
+    ow2 = int(expected_area / oh2 // dw * dw)
+    assert oh2 % dh == 0 and ow2 % dw == 0 and ow2 * oh2 <= expected_area
+    ratio2 = ow2 / oh2
+    if max(ratio / ratio1, ratio1 / ratio) < max(ratio / ratio2, ratio2 / ratio):
+        return ow1, oh1
+    return ow2, oh2
+
+
+class TI2VConfig:
+    """The constants WanTI2V reads from configs/wan_ti2v_5B.py:8-36 + shared_config.py:6-20."""
+    num_train_timesteps = 1000
+    param_dtype = torch.bfloat16
+    text_len = 512
+    vae_stride = (4, 16, 16)
+    patch_size = (1, 2, 2)
+    sample_fps = 24
+    sample_shift = 5.0
+    sample_steps = 50
+    sample_guide_scale = 5.0
+    frame_num = 121
+    sample_neg_prompt = ""
+    dit = dict(model_type="ti2v", patch_size=(1, 2, 2), text_len=512, in_dim=48, dim=3072, ffn_dim=14336, freq_dim=256,
+               text_dim=4096, out_dim=48, num_heads=24, num_layers=30, window_size=(-1, -1), qk_norm=True,
+               cross_attn_norm=True, eps=1e-6)
+
+
+class WanTI2V:
+    def __init__(self, config=TI2VConfig, checkpoint_dir=None, device_id=0, rank=0, t5_fsdp=False, dit_fsdp=False,
+                 use_sp=False, t5_cpu=False, init_on_cpu=True, convert_model_dtype=False, *, model: WanModel = None,
+                 vae=None, text_encoder: Optional[Callable] = None, device=None):
+        if t5_fsdp or dit_fsdp or use_sp:
+            raise NotImplementedError("FSDP / Ulysses SP are not part of this build (UniVid passes False for all three, "
+                                      "models/model_pipeline.py:2205-2207)")
+        if convert_model_dtype:
+            raise NotImplementedError("convert_model_dtype=True (bf16 parameters) is not UniVid's setting")
+        self.device = torch.device(device) if device is not None else torch.device(f"cuda:{device_id}")
+        self.config = config
+        self.rank = rank
+        self.t5_cpu = t5_cpu
+        self.init_on_cpu = False
+        self.num_train_timesteps = config.num_train_timesteps
+        self.param_dtype = config.param_dtype
+        self.vae_stride = config.vae_stride
+        self.patch_size = config.patch_size
+        self.sp_size = 1
+        self.sample_neg_prompt = config.sample_neg_prompt
+        self.text_encoder = text_encoder
+        self.vae = vae
+        if model is None:
+            if checkpoint_dir is None:
+                raise ValueError("pass model= (a WanModel) or checkpoint_dir=")
+            from .checkpoint import load_wan_model
+            model = load_wan_model(checkpoint_dir)
+        self.model = model.eval().requires_grad_(False).to(self.device)
+
+    # ---- prompt embeds ---------------------------------------------------------------------------------------
+    def _encode(self, prompt, embeds):
+        if embeds is not None:
+            return [e.to(self.device) for e in embeds]
+        if self.text_encoder is None:
+            raise ValueError("no text_encoder was given: pass prompt_embeds=/negative_prompt_embeds= "
+                             "(list of [len<=512, 4096] tensors)")
+        return [t.to(self.device) for t in self.text_encoder([prompt], self.device)]
+
+    def generate(self, input_prompt, img=None, size=(1280, 704), max_area=704 * 1280, frame_num=81, shift=5.0,
+                 sample_solver="unipc", sampling_steps=50, guide_scale=5.0, n_prompt="", seed=-1, offload_model=True,
+                 **kw):
+        """textimage2video.py:162-237."""
+        if img is not None:
+            return self.i2v(input_prompt=input_prompt, img=img, max_area=max_area, frame_num=frame_num, shift=shift,
+                            sample_solver=sample_solver, sampling_steps=sampling_steps, guide_scale=guide_scale,
+                            n_prompt=n_prompt, seed=seed, offload_model=offload_model, **kw)
+        return self.t2v(input_prompt=input_prompt, size=size, frame_num=frame_num, shift=shift,
+                        sample_solver=sample_solver, sampling_steps=sampling_steps, guide_scale=guide_scale,
+                        n_prompt=n_prompt, seed=seed, offload_model=offload_model, **kw)
+
+    # ---- the hot loop ----------------------------------------------------------------------------------------
+    def denoise(self, noise, context, context_null, sampling_steps, shift, guide_scale, z=None, record=None):
+        """Steps of t2v (:356-394) / i2v (:548-601) on a given noise latent [C, f, h, w] (fp32, on device).
+
+        z: first-frame latent [C, 1, h, w] switches on the i2v masking (mask2 zero on frame 0, :550-551, :598).
+        record: optional list receiving (noise_pred, latent) per step (costs one extra latent write per step).
+        Returns the final latent.
+        """
+        dev = self.device
+        sched = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
+                                            use_dynamic_shifting=False)
+        sched.set_timesteps(sampling_steps, device="cpu", shift=shift)
+        timesteps = sched.timesteps
+        latent = noise.to(device=dev, dtype=torch.float32).contiguous()
+        i2v = z is not None
+        _, mask2 = masks_like([latent], zero=i2v)
+        if i2v:
+            z = z.to(device=dev, dtype=torch.float32)
+            latent = ((1.0 - mask2[0]) * z + mask2[0] * latent).contiguous()
+        c, f, h, w = latent.shape
+        seq_len = math.ceil((h * w) / (self.patch_size[1] * self.patch_size[2]) * f / self.sp_size) * self.sp_size
+        base_mask = mask2[0][0][:, ::2, ::2].flatten()
+        for t in timesteps:
+            ts = torch.stack([t]).to(dev)
+            temp_ts = base_mask * ts                                                   # :373
+            temp_ts = torch.cat([temp_ts, temp_ts.new_ones(seq_len - temp_ts.size(0)) * ts])
+            tvec = temp_ts.unsqueeze(0)
+            cond = self.model([latent], t=tvec, context=context, seq_len=seq_len)[0]
+            uncond = self.model([latent], t=tvec, context=context_null, seq_len=seq_len)[0]
+            res = sched.step_cfg(cond.unsqueeze(0), uncond.unsqueeze(0), guide_scale, t, latent.unsqueeze(0),
+                                 want_noise_pred=record is not None)
+            if record is not None:
+                latent, npred = res[0].squeeze(0), res[1].squeeze(0)
+            else:
+                latent = res.squeeze(0)
+            if i2v:
+                latent = ((1.0 - mask2[0]) * z + mask2[0] * latent).contiguous()       # :598
+            if record is not None:
+                record.append((npred, latent.clone()))
+        return latent
+
+    def _noise(self, shape, seed):
+        seed = seed if seed >= 0 else random.randint(0, sys.maxsize)
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed)
+        return torch.randn(*shape, dtype=torch.float32, device=self.device, generator=g)
+
+    def t2v(self, input_prompt, size=(1280, 704), frame_num=121, shift=5.0, sample_solver="unipc", sampling_steps=50,
+            guide_scale=5.0, n_prompt="", seed=-1, offload_model=True, *, prompt_embeds=None, negative_prompt_embeds=None,
+            noise=None, decode=True):
+        """textimage2video.py:239-411. Returns the video [3, N, H, W] in [-1, 1] (or the latent if decode=False)."""
+        if sample_solver != "unipc":
+            raise NotImplementedError("UniVid hard-codes sample_solver='unipc' (models/model_pipeline.py:2625)")
+        F = frame_num
+        z_dim = self.model.in_dim
+        target_shape = (z_dim, (F - 1) // self.vae_stride[0] + 1, size[1] // self.vae_stride[1],
+                        size[0] // self.vae_stride[2])
+        if n_prompt == "":
+            n_prompt = self.sample_neg_prompt
+        context = self._encode(input_prompt, prompt_embeds)
+        context_null = self._encode(n_prompt, negative_prompt_embeds)
+        if noise is None:
+            noise = self._noise(target_shape, seed)
+        with torch.no_grad():
+            x0 = self.denoise(noise, context, context_null, sampling_steps, shift, guide_scale)
+            if not decode:
+                return x0
+            if self.vae is None:
+                raise ValueError("no VAE was given: pass vae= or call with decode=False")
+            return self.vae.decode([x0])[0]
+
+    def i2v(self, input_prompt, img, max_area=704 * 1280, frame_num=121, shift=5.0, sample_solver="unipc",
+            sampling_steps=40, guide_scale=5.0, n_prompt="", seed=-1, offload_model=True, *, prompt_embeds=None,
+            negative_prompt_embeds=None, noise=None, decode=True):
+        """textimage2video.py:413-619. `img` is a PIL image, or a float tensor [3, H, W] in [-1, 1] that already has
+        the output size (the PIL resize/crop of :462-477 is host-side image I/O)."""
+        if sample_solver != "unipc":
+            raise NotImplementedError("UniVid hard-codes sample_solver='unipc' (models/model_pipeline.py:2625)")
+        if self.vae is None:
+            raise ValueError("i2v needs a VAE (first-frame encode, :512)")
+        dh, dw = self.patch_size[1] * self.vae_stride[1], self.patch_size[2] * self.vae_stride[2]
+        if torch.is_tensor(img):
+            ih, iw = img.shape[-2:]
+            ow, oh = best_output_size(iw, ih, dw, dh, max_area)
+            if (ow, oh) != (iw, ih):
+                raise ValueError(f"tensor image must already be {ow}x{oh} (best_output_size); got {iw}x{ih}")
+            img_t = img.to(self.device, torch.float32).unsqueeze(1)
+        else:
+            import numpy as np
+            from PIL import Image
+            ih, iw = img.height, img.width
+            ow, oh = best_output_size(iw, ih, dw, dh, max_area)
+            scale = max(ow / iw, oh / ih)
+            img = img.resize((round(iw * scale), round(ih * scale)), Image.LANCZOS)
+            x1, y1 = (img.width - ow) // 2, (img.height - oh) // 2
+            img = img.crop((x1, y1, x1 + ow, y1 + oh))
+            arr = torch.from_numpy(np.asarray(img.convert("RGB"), dtype=np.float32) / 255.0).permute(2, 0, 1)
+            img_t = arr.sub_(0.5).div_(0.5).to(self.device).unsqueeze(1)
+        F = frame_num
+        shape = (self.model.in_dim, (F - 1) // self.vae_stride[0] + 1, oh // self.vae_stride[1], ow // self.vae_stride[2])
+        if noise is None:
+            noise = self._noise(shape, seed)
+        if n_prompt == "":
+            n_prompt = self.sample_neg_prompt
+        context = self._encode(input_prompt, prompt_embeds)
+        context_null = self._encode(n_prompt, negative_prompt_embeds)
+        with torch.no_grad():
+            z = self.vae.encode([img_t])[0]
+            x0 = self.denoise(noise, context, context_null, sampling_steps, shift, guide_scale, z=z)
+            return self.vae.decode([x0])[0] if decode else x0
