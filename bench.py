@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoise-steps/sec of the Wan2.2-TI2V-5B DiT hot path on MI355X.
+
+One "step" = exactly what WanTI2V.t2v does per timestep (reference models/wan/textimage2video.py:367-394):
+DiT forward with the prompt context + DiT forward with the negative context (CFG) + CFG combine + UniPC
+update, on a 49-frame 704x1280 latent [48,13,44,80] (L = 11 440 tokens; SURVEY.md 8(d) config 3 shape A, the
+"49-frame 720p latent" BASELINE.json's metric is quoted on), TI2V-5B dimensions (dim 3072, ffn 14336, 24 heads,
+30 layers), random-init weights (no checkpoints offline), synthetic noise / prompt-embeds resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver through torch.distributed.run (one process per GPU, RCCL): every rank denoises
+its OWN sample (independent diffusion samples shard one per GPU, no data-path collective) and the final latents
+are all-gathered once over xGMI at the end of the timed region; value = N*K / max-over-ranks time ("weak").
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LATENT = (48, 13, 44, 80)          # 49 frames, 704 x 1280 (vae stride 4,16,16)
+L_TOKENS = 13 * 22 * 40            # 11 440
+GUIDE, SHIFT, SAMPLING_STEPS = 5.0, 5.0, 50
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def dit_forward_flops(L, cfg):
+    """SURVEY.md 8(d) 'Algorithmic work per unit'."""
+    d, f, Lc, td, n = cfg["dim"], cfg["ffn_dim"], cfg["text_len"], cfg["text_dim"], cfg["num_layers"]
+    per_block = L * (12 * d * d + 4 * d * f) + 4 * Lc * d * d + 4 * L * L * d + 4 * L * Lc * d
+    return n * per_block + 2 * L * 192 * d * 2 + 2 * Lc * (td * d + d * d)
+
+
+def self_attn_flops(L, d):
+    return 4 * L * L * d
+
+
+def build_model(cfg, device, seed=0):
+    from univid_amd.wan.model import WanModel
+    with torch.device(device):  # parameters are born on the GPU (5 B fp32 = 20 GB; no host staging)
+        m = WanModel.from_config(dict(cfg, model_type="ti2v"))
+    m = m.eval().requires_grad_(False)
+    m.init_weights(seed)       # deterministic counter-based init, generated on the device
+    m.prepare()
+    return m
+
+
+def cpu_baseline(cfg, budget_s=25.0):
+    """Times the CPU restatement (oracle/, validated bit-exact against the reference modules) on this host.
+
+    A full step is 300 TFLOP (hours on a CPU), so a BOUNDED sample is timed: ONE of the 30 DiT blocks at
+    L_s tokens (L_s picked so the sample takes roughly `budget_s`), extrapolated to a step by the ratio of the
+    SURVEY 8(d) FLOP formula (x num_layers, x 2 forwards)."""
+    from oracle import wan_dit
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    c1 = dict(cfg, num_layers=1)
+    sd = wan_dit.make_state_dict(c1, 0)
+    g = torch.Generator().manual_seed(0)
+    ctx = torch.randn(1, cfg["text_len"], cfg["dim"], generator=g).to(torch.bfloat16)
+    freqs = wan_dit.rope_table(cfg["dim"] // cfg["num_heads"])
+
+    def run(f, h, w):
+        L = f * h * w
+        x = torch.randn(1, L, cfg["dim"], generator=g)
+        e0 = torch.randn(1, 1, 6, cfg["dim"], generator=g).expand(1, L, 6, cfg["dim"]) * 0.1
+        t0 = time.time()
+        with torch.no_grad():
+            wan_dit.block_forward(sd, "blocks.0.", x, e0, torch.tensor([L]), torch.tensor([[f, h, w]]), freqs, ctx,
+                                  cfg["num_heads"], cfg["eps"])
+        return L, time.time() - t0
+
+    def block_flops(L):
+        return dit_forward_flops(L, c1) - (2 * L * 192 * cfg["dim"] * 2 + 2 * cfg["text_len"] * (cfg["text_dim"] * cfg["dim"] + cfg["dim"] ** 2))
+
+    run(1, 8, 8)                                   # warm the thread pool / oneDNN primitives
+    Lp, tp = run(2, 16, 16)                        # probe: 512 tokens
+    rate = block_flops(Lp) / tp
+    choice = (1, 8, 16)
+    for grid in [(13, 22, 40), (13, 15, 26), (4, 22, 40), (2, 22, 40), (1, 22, 40), (1, 16, 16)]:
+        L = grid[0] * grid[1] * grid[2]
+        if block_flops(L) / rate <= budget_s * 1.5:
+            choice = grid
+            break
+    Ls, ts = run(*choice)
+    full_step_s = ts * (2 * dit_forward_flops(L_TOKENS, cfg)) / block_flops(Ls)
+    return {"value": 1.0 / full_step_s, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/wan_dit.block_forward: 1 of {cfg['num_layers']} DiT blocks at L={Ls} tokens "
+                      f"(grid {choice}) in {ts:.1f} s on {cores} threads (bf16 autocast dtype flow), extrapolated to one "
+                      f"CFG step at L={L_TOKENS} by the SURVEY 8(d) FLOP ratio"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer DiT blocks (result is NOT the metric)")
+    ap.add_argument("--kernel-times", action="store_true", help="HIP-event timing of every kernel class (adds ~1%% overhead)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1 and world == 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from oracle.wan_dit import TI2V_5B_CFG  # constants only (configs/wan_ti2v_5B.py:17-29)
+    from univid_amd import _lib
+    from univid_amd.wan.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    cfg = dict(TI2V_5B_CFG)
+    if args.layers:
+        cfg["num_layers"] = args.layers
+    _lib.init()
+    model = build_model(cfg, device, seed=0)
+
+    g = torch.Generator(device=device).manual_seed(42 + rank)
+    latent = torch.randn(*LATENT, device=device, generator=g)
+    ctx = [torch.randn(77, cfg["text_dim"], device=device, generator=g) * 0.1]
+    ctx_null = [torch.randn(12, cfg["text_dim"], device=device, generator=g) * 0.1]
+    sched = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1)
+    sched.set_timesteps(SAMPLING_STEPS, device="cpu", shift=SHIFT)
+    timesteps = sched.timesteps
+    seq_len = L_TOKENS
+    assert args.warmup + args.steps <= len(timesteps)
+
+    def one_step(i, lat):
+        t = timesteps[i]
+        tvec = torch.full((1, seq_len), float(t), device=device)
+        cond = model([lat], t=tvec, context=ctx, seq_len=seq_len)[0]
+        uncond = model([lat], t=tvec, context=ctx_null, seq_len=seq_len)[0]
+        return sched.step_cfg(cond.unsqueeze(0), uncond.unsqueeze(0), GUIDE, t, lat.unsqueeze(0)).squeeze(0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            latent = one_step(i, latent)
+        # live HIP-event timing of the dominant kernel (self-attention) on the launch stream
+        _lib.PROFILE = {"uv_flash_attn_bf16": []}
+        _lib.PROFILE_ALL = bool(args.kernel_times)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):
+            latent = one_step(i, latent)
+        if world > 1:  # the single collective of the path: final latents to every rank (8.8 MB/GPU)
+            gathered = [torch.empty_like(latent) for _ in range(world)]
+            dist.all_gather(gathered, latent)
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = _lib.PROFILE
+        _lib.PROFILE, _lib.PROFILE_ALL = None, False
+
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+    ok = bool(torch.isfinite(latent).all().item())
+
+    if rank == 0:
+        ktimes = {}
+        for name, evs in prof.items():
+            if evs:
+                ms = [s.elapsed_time(e) for s, e, _ in evs]
+                ktimes[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms),
+                                "flops": sum(f for _, _, f in evs)}
+        att = ktimes.get("uv_flash_attn_bf16")
+        roofline = None
+        if att:
+            # self-attention launches only (Lk == L); cross-attention launches (Lk = 512) are tagged with fewer flops
+            self_ev = [(s, e, f) for s, e, f in prof["uv_flash_attn_bf16"] if f >= self_attn_flops(L_TOKENS, cfg["dim"]) * 0.99]
+            avg_ms = sum(s.elapsed_time(e) for s, e, _ in self_ev) / len(self_ev)
+            achieved = self_attn_flops(L_TOKENS, cfg["dim"]) / (avg_ms * 1e-3) / 1e12
+            roofline = {"kernel": "flash_attn_fwd_kernel<128> (self-attention, Lq=Lk=11440, 24 heads)", "bound": "mfma",
+                        "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(self_ev),
+                        "flops_per_launch": self_attn_flops(L_TOKENS, cfg["dim"])}
+        step_flops = 2 * dit_forward_flops(L_TOKENS, cfg)
+        out = {
+            "metric": "denoise_steps_per_sec", "value": round(world * args.steps / dt_max, 4), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "49-frame 704x1280 latent [48,13,44,80], L=11440 tokens; TI2V-5B DiT (dim 3072, ffn 14336, "
+                                   "24 heads, %d layers); 1 step = cond+uncond forward + CFG + UniPC; one sample per GPU" % cfg["num_layers"],
+                       "samples_per_gpu": 1, "guide_scale": GUIDE, "shift": SHIFT, "parallelism": f"replicas x{world}, all-gather of final latents"},
+            "step_tflop": round(step_flops / 1e12, 1),
+            "model_tflops_per_gpu": round(step_flops * args.steps / dt_max / 1e12, 1),
+            "mfma_frac_whole_step": round(step_flops * args.steps / dt_max / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "finite": ok,
+            "roofline": roofline,
+        }
+        if args.kernel_times:
+            out["kernel_times"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in ktimes.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dict(TI2V_5B_CFG))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

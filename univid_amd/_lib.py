@@ -97,11 +97,25 @@ def ptr(t):
     return _c.c_void_p(t.data_ptr())
 
 
-def call(name, *args):
+# Optional live kernel timing (bench.py): PROFILE = {entry_point: []} times those entry points with HIP events
+# recorded on the launch stream; PROFILE_ALL times every entry point. Off (None) in normal use.
+PROFILE = None
+PROFILE_ALL = False
+
+
+def call(name, *args, flops=0):
     lib = init()
+    prof = PROFILE
+    timed = prof is not None and (PROFILE_ALL or name in prof)
+    if timed:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise UnividHipError(f"{name} failed ({rc}): {lib.uv_last_error().decode()}")
+    if timed:
+        e.record()
+        prof.setdefault(name, []).append((s, e, flops))
 
 
 # ---- thin typed wrappers (tensor checks live here so the C side only sees valid pointers) -----------------------
@@ -122,7 +136,7 @@ def gemm_bf16(a, w, bias, out, epi, M=None, gate=None, gate_tid=None, tile_cfg=0
     M = a.shape[0] if M is None else M
     N, K = w.shape
     call("uv_gemm_bf16_nt", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), M, N, K, epi, ptr(out), out.stride(0),
-         ptr(gate), ptr(gate_tid), 0 if gate is None else gate.stride(0), tile_cfg, stream_ptr())
+         ptr(gate), ptr(gate_tid), 0 if gate is None else gate.stride(0), tile_cfg, stream_ptr(), flops=2 * M * N * K)
     return out
 
 
@@ -140,7 +154,7 @@ def flash_attn(q, k, vt, out, Lq, Lk, H, D, scale):
     for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (out, "out")):
         _chk(t, torch.bfloat16, "flash_attn." + n)
     call("uv_flash_attn_bf16", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(vt), vt.stride(0), ptr(out), out.stride(0),
-         Lq, Lk, H, D, float(scale), stream_ptr())
+         Lq, Lk, H, D, float(scale), stream_ptr(), flops=4 * Lq * Lk * H * D)
     return out
 
 

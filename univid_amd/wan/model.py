@@ -334,8 +334,9 @@ class WanModel(nn.Module):
         if d not in (64, 128):
             raise NotImplementedError(f"head_dim {d}: the attention kernel is built for 64 and 128")
         # plain attribute like the reference (model.py:397-405), so .to() does not change its dtype
-        self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
-                                rope_params(1024, 2 * (d // 6))], dim=1)
+        with torch.device("cpu"):  # fp64 host table, also when the module is built under torch.device('cuda')
+            self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
+                                    rope_params(1024, 2 * (d // 6))], dim=1)
         self._prep = None
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
 
