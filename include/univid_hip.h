@@ -103,6 +103,31 @@ int uv_unipc_corrector(const float* x_last, const float* m0, const float* m_prev
 int uv_unipc_predictor(const float* x, const float* m0, const float* m_prev, float* out, float r, float c1, float c2,
                        float rk, int order, long n, void* stream);
 
+/* ---- VAE (fp32, channels-last [T, H, W, C]) -------------------------------------------------------------------- */
+/* Causal 3D / 2D convolution as implicit GEMM on the exact-f32 MFMA. Replaces CausalConv3d (vae2_2.py:17-42) and the
+ * Resample convolutions (vae2_2.py:86-108, 153-155). in: input ring [Tin, Hin, Win, ld_in]; w: [Cout, kt*kh*kw*Cin]
+ * (tap-major, channel-minor); out rows = output pixels (t,h,w) row-major, [M, ldo]. Input frame of tap dt for output
+ * frame t is t*st + dt + t_off; rows/cols are h*sh + dh - ph, w*sw + dw - pw, out-of-range taps contribute zero.
+ * up=1: the input is read through a nearest-exact 2x spatial upsample (Hin/Win are the PRE-upsample sizes).
+ * interleave=1: output channel halves become consecutive frames (Resample.time_conv, vae2_2.py:143-151).
+ * Cin % 32 == 0 (zero-pad channels), Cout % 4 == 0. */
+int uv_conv3d_f32(const float* in, long ld_in, int Tin, int Hin, int Win, const float* w, const float* bias, float* out,
+                  long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw,
+                  int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr, void* stream);
+/* y = x / max(||x||,1e-12) * sqrt(C) * gamma [-> SiLU] per pixel (RMS_norm + SiLU, vae2_2.py:45-59, 201-206) */
+int uv_vae_rms_silu(const float* in, long ld_in, const float* gamma, float* out, long ld_out, long P, int C, int do_silu,
+                    void* stream);
+/* in-place row softmax of x*scale (AttentionBlock's SDPA, vae2_2.py:267-271) */
+int uv_softmax_rows_f32(float* x, long ld, int R, int n, float scale, void* stream);
+/* out += DupUp3D(x) (vae2_2.py:390-412); out += AvgDown3D(x) (vae2_2.py:335-367) */
+int uv_vae_dupup_add(const float* x, float* out, int T, int H, int W, int Cin, int Cout, int ft, int drop, void* stream);
+int uv_vae_avgdown_add(const float* x, float* out, int T, int H, int W, int Cin, int Cout, int ft, int fs, void* stream);
+/* latent / video layout conversions at the VAE boundary (vae2_2.py:280-313, 803-808, 814-818, 1045) */
+int uv_vae_latent_in(const float* z, const float* mean, const float* inv_std, float* out, long ld, int Z, long P, void* stream);
+int uv_vae_latent_out(const float* mu, long ld, const float* mean, const float* inv_std, float* out, int Z, long P, void* stream);
+int uv_vae_video_in(const float* vid, float* out, long ld, int F, int H, int W, int f0, int T, void* stream);
+int uv_vae_video_out(const float* y, long ld, float* vid, int F, int Hp, int Wp, int f0, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,6 +185,77 @@ def check_dit():
             stats(f"dit heads{cfg['num_heads']} t={tmode}", out, ref[0])
 
 
+def check_vae():
+    print("== VAE vs oracle")
+    from oracle import wan_vae
+    from univid_amd.wan.vae2_2 import WanVAE_
+    cfg = wan_vae.SMALL_CFG
+    sd = wan_vae.make_state_dict(cfg, 1)
+    m = WanVAE_(dim=cfg["dim"], dec_dim=cfg["dec_dim"], z_dim=cfg["z_dim"], dim_mult=cfg["dim_mult"],
+                temperal_downsample=cfg["temperal_downsample"])
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    ora = wan_vae.WanVAE(sd, cfg)
+    scale = wan_vae.scale_tensors()
+    scale_d = [s.to(dev) for s in scale]
+    g = torch.Generator().manual_seed(3)
+    for shape in [(3, 9, 32, 48), (3, 5, 64, 32), (3, 1, 32, 32)]:
+        vid = torch.tanh(torch.randn(*shape, generator=g))
+        with torch.no_grad():
+            ref = ora.encode(vid.unsqueeze(0), scale)
+            got = m.encode(vid.unsqueeze(0).to(dev), scale_d)
+        stats(f"encode {shape}", got, ref)
+    for shape in [(48, 3, 2, 3), (48, 2, 4, 2), (48, 1, 2, 2)]:
+        z = torch.randn(1, *shape, generator=g)
+        with torch.no_grad():
+            ref = ora.decode(z, scale).clamp(-1, 1)
+            got = m.decode(z.to(dev), scale_d)
+        stats(f"decode {shape}", got, ref)
+    # per-op: one conv against F.conv3d
+    import torch.nn.functional as F
+    x = torch.randn(1, 64, 5, 6, 7)
+    w = torch.randn(96, 64, 3, 3, 3) * 0.05
+    b = torch.randn(96)
+    ref = wan_vae.causal_conv3d(x, w, b, pad=(1, 1, 1))
+    from univid_amd.wan.vae2_2 import _Engine, _ConvOp
+    import torch.nn as nn
+    conv = nn.Conv3d(64, 96, 3)
+    conv.weight.data.copy_(w); conv.bias.data.copy_(b)
+    conv = conv.to(dev)
+    op = _ConvOp(conv)
+    ring = op.ring(6, 7, 5)
+    ring[2:7].copy_(x[0].permute(1, 2, 3, 0).to(dev))
+    out = torch.empty(5, 6, 7, 96, device=dev)
+    _lib.call("uv_conv3d_f32", _lib.ptr(ring), 64, 7, 6, 7, _lib.ptr(op.w), _lib.ptr(op.b), _lib.ptr(out), 96, 5, 6, 7, 64, 96, 3, 3, 3,
+              1, 1, 1, 0, 1, 1, 0, 0, None, 0, _lib.stream_ptr())
+    stats("conv3d 3x3x3 64->96", out.permute(3, 0, 1, 2), ref[0])
+
+
+def perf_vae():
+    print("== VAE perf (full width)")
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    vae = Wan2_2_VAE(device=dev)
+    for shape in [(48, 2, 16, 16), (48, 3, 45, 80)]:
+        z = torch.randn(*shape, device=dev)
+        torch.cuda.synchronize(); t0 = time.time()
+        with torch.no_grad():
+            v = vae.decode([z])[0]
+        torch.cuda.synchronize(); dt = time.time() - t0
+        print(f"  decode {shape} -> {tuple(v.shape)} in {dt:.3f} s, finite={bool(torch.isfinite(v).all())}", flush=True)
+    _lib.PROFILE, _lib.PROFILE_ALL = {}, True
+    z = torch.randn(48, 3, 45, 80, device=dev)
+    torch.cuda.synchronize(); t0 = time.time()
+    with torch.no_grad():
+        v = vae.decode([z])[0]
+    torch.cuda.synchronize(); dt = time.time() - t0
+    prof = _lib.PROFILE; _lib.PROFILE, _lib.PROFILE_ALL = None, False
+    print(f"  decode again: {dt:.3f} s for {v.shape[1]} frames 720x1280 -> {v.numel()*4/dt/1e9:.3f} GB/s")
+    for name, evs in prof.items():
+        ms = [s.elapsed_time(e) for s, e, _ in evs]
+        fl = sum(f for _, _, f in evs)
+        print(f"    {name:24s} launches={len(ms):5d} total={sum(ms):9.2f} ms  {fl/ (sum(ms)*1e-3)/1e12 if fl else 0:.1f} TFLOP/s")
+
+
 def perf():
     print("== perf (full-size shapes)")
     L, C, F = 11440, 3072, 14336
@@ -212,11 +283,11 @@ def perf():
 
 if __name__ == "__main__":
     _lib.init()
-    which = sys.argv[1:] or ["gemm", "gemm_f32", "attn", "glue", "dit", "perf"]
+    which = sys.argv[1:] or ["gemm", "gemm_f32", "attn", "glue", "dit", "vae", "perf"]
     for w in which:
         try:
             {"gemm": check_gemm, "gemm_f32": check_gemm_f32, "attn": check_attn, "glue": check_glue, "dit": check_dit,
-             "perf": perf}[w]()
+             "vae": check_vae, "perf_vae": perf_vae, "perf": perf}[w]()
         except Exception as ex:  # keep going: one round trip should tell as much as possible
             import traceback
             traceback.print_exc()

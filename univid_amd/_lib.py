@@ -36,6 +36,16 @@ SIGNATURES = {
     "uv_cfg_convert": [_P, _P, _P, _F, _F, _P, _P, _L, _P],
     "uv_unipc_corrector": [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _L, _P],
     "uv_unipc_predictor": [_P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _P],
+    "uv_conv3d_f32": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                      _P, _L, _P],
+    "uv_vae_rms_silu": [_P, _L, _P, _P, _L, _L, _I, _I, _P],
+    "uv_softmax_rows_f32": [_P, _L, _I, _I, _F, _P],
+    "uv_vae_dupup_add": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "uv_vae_avgdown_add": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "uv_vae_latent_in": [_P, _P, _P, _P, _L, _I, _L, _P],
+    "uv_vae_latent_out": [_P, _L, _P, _P, _P, _I, _L, _P],
+    "uv_vae_video_in": [_P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "uv_vae_video_out": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
 }
 _RESTYPE = {"uv_last_error": _c.c_char_p}
 

@@ -67,6 +67,10 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    # a kernel whose host stub was silently dropped shows up as an undefined symbol only at dlopen time
+    r = subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({LIB!r})"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{LIB} does not load:\n{r.stderr[-2000:]}")
     if verbose:
         print(f"[univid_amd.build] {LIB} ({os.path.getsize(LIB) >> 10} KiB, {len(objs)} objects)")
     return LIB

@@ -1,0 +1,215 @@
+// Causal 3D / 2D convolution of the Wan2.2 VAE as an implicit GEMM on the exact-f32 MFMA
+// (v_mfma_f32_16x16x4_f32), channels-last activations.
+//
+//   out[pixel, co] = bias[co] + sum_{tap, ci} in[pixel + tap, ci] * w[co, tap, ci]   (+ residual)
+//   M = output pixels (t, h, w), N = Cout, K = taps * Cin; A rows are GATHERED straight from the input
+//   ring by the global_load_lds source address (one 16-byte chunk of one tap per lane), out-of-range taps
+//   (spatial zero padding, causal time padding) read a zero page instead.
+//
+// Replaces (reference, fp32 nn.Conv3d / nn.Conv2d through cuDNN):
+//   CausalConv3d.forward            models/wan/utils/modules/vae2_2.py:34-42  (time left-pad / cache prepend)
+//   Resample: Upsample(nearest-exact 2x) + Conv2d 3x3           vae2_2.py:86-96, 153-155   (up=1: the 2x
+//       upsample is folded into the gather, the upsampled tensor is never materialised)
+//   Resample: ZeroPad2d(0,1,0,1) + Conv2d 3x3 stride 2          vae2_2.py:99-108
+//   Resample.time_conv 3x1x1 (C -> 2C, then frame interleave)   vae2_2.py:97-98, 143-151  (interleave=1:
+//       the reshape/stack of :148-151 is done by the epilogue's store addresses)
+//
+// The reference's per-convolution feature cache (CACHE_T = 2 frames, vae2_2.py:219-232) is realised by the
+// caller as an input RING [2 + T, H, W, C]: frames 0..1 hold the cached frames (zeros before the first
+// chunk = the causal zero padding), the producer writes frames 2.., and `t_off` selects the first ring frame
+// a kernel tap reads.
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_c;
+
+struct ConvArgs {
+    const float* in;     // [Tin, Hin, Win, ld_in] channels-last
+    const float* w;      // [Cout, taps * Cin]
+    const float* bias;   // [Cout] or nullptr
+    const float* resid;  // [M, ldr] or nullptr
+    float* out;
+    const float* zeros;
+    long ld_in, ldo, ldr;
+    int Tout, Hout, Wout, Tin, Hin, Win;
+    int Cin, Cout, kt, kh, kw, st, sh, sw, t_off, ph, pw, up, interleave;
+    int M, tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // n tiles fastest: blocks that share an A panel (the expensive gather) are adjacent
+    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int K = p.kt * p.kh * p.kw * p.Cin;
+
+    const int srow = lane >> 3, pchunk = lane & 7;
+    int a_t[A_INSTR], a_h[A_INSTR], a_w[A_INSTR], a_c[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int row = (i * NW + wave) * 8 + srow;
+        a_c[i] = (pchunk ^ ((row >> 1) & 7)) * 4;
+        const int m = min(m0 + row, p.M - 1);
+        a_w[i] = m % p.Wout;
+        const int r = m / p.Wout;
+        a_h[i] = r % p.Hout;
+        a_t[i] = r / p.Hout;
+    }
+    const float* w_src[W_INSTR];
+    int w_c[W_INSTR];
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i) {
+        const int row = (i * NW + wave) * 8 + srow;
+        w_c[i] = (pchunk ^ ((row >> 1) & 7)) * 4;
+        w_src[i] = p.w + (long)min(n0 + row, p.Cout - 1) * K + w_c[i];
+    }
+    const int Hlim = p.up ? 2 * p.Hin : p.Hin, Wlim = p.up ? 2 * p.Win : p.Win;
+    const long frame = (long)p.Hin * p.Win * p.ld_in;
+
+    // running (tap, channel) position of the NEXT k-tile to stage; a k-tile (32 channels) never straddles taps
+    int s_ci = 0, s_dt = 0, s_dh = 0, s_dw = 0;
+#define UV_CONV_STAGE(KT, BUF)                                                                                        \
+    do {                                                                                                              \
+        char* sbase = smem + (BUF) * STAGE;                                                                           \
+        _Pragma("unroll") for (int i = 0; i < A_INSTR; ++i) {                                                         \
+            const int it = a_t[i] * p.st + s_dt + p.t_off;                                                            \
+            int ih = a_h[i] * p.sh + s_dh - p.ph;                                                                     \
+            int iw = a_w[i] * p.sw + s_dw - p.pw;                                                                     \
+            const bool ok = (unsigned)it < (unsigned)p.Tin && (unsigned)ih < (unsigned)Hlim &&                        \
+                            (unsigned)iw < (unsigned)Wlim;                                                            \
+            if (p.up) { ih >>= 1; iw >>= 1; }                                                                         \
+            const float* src = ok ? p.in + it * frame + ((long)ih * p.Win + iw) * p.ld_in + s_ci + a_c[i] : p.zeros;  \
+            __builtin_amdgcn_global_load_lds(src, (lds_void_c*)(sbase + (i * NW + wave) * 1024), 16, 0, 0);           \
+        }                                                                                                             \
+        const int koff = (KT) * 32;                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < W_INSTR; ++i) {                                                         \
+            const float* wsrc = w_src[i] + koff;                                                                      \
+            __builtin_amdgcn_global_load_lds(wsrc, (lds_void_c*)(sbase + A_BYTES + (i * NW + wave) * 1024), 16, 0, 0);\
+        }                                                                                                             \
+        s_ci += 32;                                                                                                   \
+        if (s_ci >= p.Cin) {                                                                                          \
+            s_ci = 0;                                                                                                 \
+            if (++s_dw == p.kw) { s_dw = 0; if (++s_dh == p.kh) { s_dh = 0; ++s_dt; } }                               \
+        }                                                                                                             \
+    } while (0)
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[TM], a_key[TM], w_off[TN], w_key[TN];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int row = wm * (BM / WM) + j * 16 + frow;
+        a_off[j] = row * 128; a_key[j] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int row = wn * (BN / WN) + i * 16 + frow;
+        w_off[i] = A_BYTES + row * 128; w_key[i] = (row >> 1) & 7;
+    }
+
+    const int nk = K / 32;
+    UV_CONV_STAGE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) UV_CONV_STAGE(kt + 1, buf ^ 1);
+        const char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f32x4 af[TM], wf[TN];
+            const int c = ks * 4 + fq;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) af[j] = *(const f32x4*)(base + a_off[j] + ((c ^ a_key[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wf[i] = *(const f32x4*)(base + w_off[i] + ((c ^ w_key[i]) << 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], af[j][e], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const int hw = p.Hout * p.Wout;
+    const int chalf = p.Cout >> 1;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * (BM / WM) + j * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + wn * (BN / WN) + i * 16 + 4 * fq;
+            if (n >= p.Cout) continue;
+            f32x4 v = acc[i][j];
+            if (p.bias) {
+                const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += b[e];
+            }
+            if (p.interleave) {
+                // channel halves become consecutive frames: out frame = 2*t + (n >= C/2)   vae2_2.py:148-151
+                const int t = m / hw, pix = m - t * hw;
+                const int half = n >= chalf;
+                *(f32x4*)(p.out + ((long)(2 * t + half) * hw + pix) * p.ldo + (n - half * chalf)) = v;
+            } else {
+                if (p.resid) {
+                    const f32x4 rr = *(const f32x4*)(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                }
+                *(f32x4*)(p.out + (long)m * p.ldo + n) = v;
+            }
+        }
+    }
+}
+
+const float* uv_zero_page();
+
+extern "C" int uv_conv3d_f32(const float* in, long ld_in, int Tin, int Hin, int Win, const float* w, const float* bias,
+                             float* out, long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh,
+                             int kw, int st, int sh, int sw, int t_off, int ph, int pw, int up, int interleave,
+                             const float* resid, long ldr, void* stream) {
+    UV_CHECK_ARG(in && w && out, "uv_conv3d_f32: null pointer");
+    UV_CHECK_ARG(Cin % 32 == 0, "uv_conv3d_f32: Cin=%d must be a multiple of 32 (pad channels with zeros)", Cin);
+    UV_CHECK_ARG(Cout % 4 == 0, "uv_conv3d_f32: Cout=%d must be a multiple of 4", Cout);
+    UV_CHECK_ARG(ld_in % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0 && ld_in >= Cin, "uv_conv3d_f32: bad leading dimensions");
+    UV_CHECK_ARG(Tout > 0 && Hout > 0 && Wout > 0 && kt > 0 && kh > 0 && kw > 0, "uv_conv3d_f32: bad geometry");
+    UV_CHECK_ARG(!interleave || (Cout % 8 == 0 && !resid), "uv_conv3d_f32: interleave needs Cout %% 8 == 0 and no residual");
+    UV_CHECK_ARG((((uintptr_t)in | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)resid) & 15) == 0,
+                 "uv_conv3d_f32: pointers must be 16-byte aligned");
+    ConvArgs a;
+    a.in = in; a.w = w; a.bias = bias; a.resid = resid; a.out = out; a.zeros = uv_zero_page();
+    UV_CHECK_ARG(a.zeros, "uv_conv3d_f32: zero page missing (call uv_init)");
+    a.ld_in = ld_in; a.ldo = ldo; a.ldr = ldr;
+    a.Tout = Tout; a.Hout = Hout; a.Wout = Wout; a.Tin = Tin; a.Hin = Hin; a.Win = Win;
+    a.Cin = Cin; a.Cout = Cout; a.kt = kt; a.kh = kh; a.kw = kw; a.st = st; a.sh = sh; a.sw = sw;
+    a.t_off = t_off; a.ph = ph; a.pw = pw; a.up = up; a.interleave = interleave;
+    a.M = Tout * Hout * Wout;
+    constexpr int BM = 128, BN = 128;
+    a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (Cout + BN - 1) / BN;
+    auto kern = conv3d_f32_kernel<BM, BN, 2, 2>;
+    const size_t lds = 2 * (BM + BN) * 128;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, (hipStream_t)stream, a);
+    UV_CHECK_LAUNCH("uv_conv3d_f32");
+    return 0;
+}

@@ -1,0 +1,237 @@
+// HBM-bound glue of the Wan2.2 VAE on channels-last fp32 activations ([T, H, W, C], one wave per pixel row).
+//
+// Replaces (reference, PyTorch eager, fp32):
+//   RMS_norm + SiLU                      models/wan/utils/modules/vae2_2.py:45-59, 201-206
+//   AvgDown3D / DupUp3D shortcuts        vae2_2.py:316-412
+//   softmax of the single-head AttentionBlock (F.scaled_dot_product_attention)   vae2_2.py:255-277
+//   patchify / unpatchify, latent (de)normalisation, clamp    vae2_2.py:280-313, 803-808, 814-818, 1045
+#include "common.h"
+
+// y = x / max(||x||_2, 1e-12) * sqrt(C) * gamma  [-> SiLU]      (F.normalize(x, dim=C) * scale * gamma)
+template <int MAXV>
+__global__ __launch_bounds__(256) void vae_rms_silu_kernel(const float* in, long ld_in, const float* gamma, float* out,
+                                                          long ld_out, long P, int C, int do_silu) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= P) return;
+    const float* xr = in + row * ld_in;
+    const int nv = C >> 2;  // float4 count
+    f32x4 v[MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = i * 64 + lane;
+        if (c4 < nv) {
+            v[i] = *(const f32x4*)(xr + c4 * 4);
+            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+    }
+    const float denom = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    const float scale = sqrtf((float)C);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = i * 64 + lane;
+        if (c4 < nv) {
+            const f32x4 g = *(const f32x4*)(gamma + c4 * 4);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = __fmul_rn(__fmul_rn(__fdiv_rn(v[i][e], denom), scale), g[e]);
+                if (do_silu) t = silu_f32(t);
+                y[e] = t;
+            }
+            *(f32x4*)(out + row * ld_out + c4 * 4) = y;
+        }
+    }
+}
+
+extern "C" int uv_vae_rms_silu(const float* in, long ld_in, const float* gamma, float* out, long ld_out, long P, int C,
+                               int do_silu, void* stream) {
+    UV_CHECK_ARG(in && gamma && out && P > 0, "uv_vae_rms_silu: bad arguments");
+    UV_CHECK_ARG(C % 4 == 0 && C <= 2048 && ld_in % 4 == 0 && ld_out % 4 == 0, "uv_vae_rms_silu: C=%d unsupported", C);
+    const dim3 grid((unsigned)((P + 3) / 4)), block(256);
+    if (C <= 512) hipLaunchKernelGGL(vae_rms_silu_kernel<2>, grid, block, 0, (hipStream_t)stream, in, ld_in, gamma, out, ld_out, P, C, do_silu);
+    else hipLaunchKernelGGL(vae_rms_silu_kernel<8>, grid, block, 0, (hipStream_t)stream, in, ld_in, gamma, out, ld_out, P, C, do_silu);
+    UV_CHECK_LAUNCH("uv_vae_rms_silu");
+    return 0;
+}
+
+// in-place softmax over rows of x * scale (fp32), one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* x, long ld, int R, int n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float* xr = x + (long)row * ld;
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, xr[i] * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) {
+        const float e = expf(xr[i] * scale - m);
+        xr[i] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int i = lane; i < n; i += 64) xr[i] *= inv;
+}
+
+extern "C" int uv_softmax_rows_f32(float* x, long ld, int R, int n, float scale, void* stream) {
+    UV_CHECK_ARG(x && R > 0 && n > 0, "uv_softmax_rows_f32: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, R, n, scale);
+    UV_CHECK_LAUNCH("uv_softmax_rows_f32");
+    return 0;
+}
+
+// DupUp3D (vae2_2.py:390-412) added onto the main path: out[t',h',w',co] += x[t'/ft, h'/2, w'/2, j / repeats],
+// j = ((co*ft + t'%ft)*2 + h'%2)*2 + w'%2, repeats = Cout*ft*4 / Cin; `drop` leading frames are skipped
+// (first_chunk: ft-1).  x: [T, H, W, Cin]; out: [T*ft - drop, 2H, 2W, Cout].
+__global__ void dupup_add_kernel(const float* x, float* out, int T, int H, int W, int Cin, int Cout, int ft, int drop) {
+    const int To = T * ft - drop, Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)To * Ho * Wo * Cout;
+    const int repeats = Cout * ft * 4 / Cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        long r = i / Cout;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int to = (int)(r / Ho) + drop;
+        const int j = ((co * ft + to % ft) * 2 + (ho & 1)) * 2 + (wo & 1);
+        out[i] += x[(((long)(to / ft) * H + (ho >> 1)) * W + (wo >> 1)) * Cin + j / repeats];
+    }
+}
+
+extern "C" int uv_vae_dupup_add(const float* x, float* out, int T, int H, int W, int Cin, int Cout, int ft, int drop,
+                                void* stream) {
+    UV_CHECK_ARG(x && out && (Cout * ft * 4) % Cin == 0, "uv_vae_dupup_add: bad arguments");
+    const long total = (long)(T * ft - drop) * 2 * H * 2 * W * Cout;
+    hipLaunchKernelGGL(dupup_add_kernel, dim3((unsigned)min((total + 255) / 256, (long)8192)), dim3(256), 0,
+                       (hipStream_t)stream, x, out, T, H, W, Cin, Cout, ft, drop);
+    UV_CHECK_LAUNCH("uv_vae_dupup_add");
+    return 0;
+}
+
+// AvgDown3D (vae2_2.py:335-367) added onto the main path: out[t,h,w,co] += mean_g x[cin, t*ft+a-pad, h*fs+b, w*fs+c],
+// (cin,a,b,c) = unravel(co*group + g, (Cin, ft, fs, fs)); frames with negative index (front padding) read zero.
+__global__ void avgdown_add_kernel(const float* x, float* out, int T, int H, int W, int Cin, int Cout, int ft, int fs) {
+    const int pad = (ft - T % ft) % ft;
+    const int To = (T + pad) / ft, Ho = H / fs, Wo = W / fs;
+    const int factor = ft * fs * fs, group = Cin * factor / Cout;
+    const long total = (long)To * Ho * Wo * Cout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        long r = i / Cout;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int to = (int)(r / Ho);
+        float s = 0.f;
+        for (int g = 0; g < group; ++g) {
+            const int j = co * group + g;
+            const int c = j % fs, b = (j / fs) % fs, a = (j / (fs * fs)) % ft, cin = j / factor;
+            const int ti = to * ft + a - pad;
+            if (ti >= 0) s += x[(((long)ti * H + ho * fs + b) * W + wo * fs + c) * Cin + cin];
+        }
+        out[i] += s / (float)group;
+    }
+}
+
+extern "C" int uv_vae_avgdown_add(const float* x, float* out, int T, int H, int W, int Cin, int Cout, int ft, int fs,
+                                  void* stream) {
+    UV_CHECK_ARG(x && out && (Cin * ft * fs * fs) % Cout == 0 && H % fs == 0 && W % fs == 0, "uv_vae_avgdown_add: bad arguments");
+    const int pad = (ft - T % ft) % ft;
+    const long total = (long)((T + pad) / ft) * (H / fs) * (W / fs) * Cout;
+    hipLaunchKernelGGL(avgdown_add_kernel, dim3((unsigned)min((total + 255) / 256, (long)8192)), dim3(256), 0,
+                       (hipStream_t)stream, x, out, T, H, W, Cin, Cout, ft, fs);
+    UV_CHECK_LAUNCH("uv_vae_avgdown_add");
+    return 0;
+}
+
+// decode entry: z [Z, f, h, w] -> channels-last rows [f*h*w, ld] of z / inv_std + mean   (vae2_2.py:814-816)
+__global__ void latent_in_kernel(const float* z, const float* mean, const float* inv_std, float* out, long ld, int Z, long P) {
+    const long total = P * Z;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Z);
+        const long pix = i / Z;
+        out[pix * ld + c] = __fadd_rn(__fdiv_rn(z[(long)c * P + pix], inv_std[c]), mean[c]);
+    }
+}
+
+extern "C" int uv_vae_latent_in(const float* z, const float* mean, const float* inv_std, float* out, long ld, int Z, long P,
+                                void* stream) {
+    UV_CHECK_ARG(z && mean && inv_std && out && ld >= Z, "uv_vae_latent_in: bad arguments");
+    hipLaunchKernelGGL(latent_in_kernel, dim3((unsigned)min((P * Z + 255) / 256, (long)4096)), dim3(256), 0,
+                       (hipStream_t)stream, z, mean, inv_std, out, ld, Z, P);
+    UV_CHECK_LAUNCH("uv_vae_latent_in");
+    return 0;
+}
+
+// encode exit: rows [P, ld] (first Z channels = mu) -> [Z, f, h, w] of (mu - mean) * inv_std   (vae2_2.py:803-806)
+__global__ void latent_out_kernel(const float* mu, long ld, const float* mean, const float* inv_std, float* out, int Z, long P) {
+    const long total = P * Z;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i % P;
+        const int c = (int)(i / P);
+        out[i] = __fmul_rn(__fsub_rn(mu[pix * ld + c], mean[c]), inv_std[c]);
+    }
+}
+
+extern "C" int uv_vae_latent_out(const float* mu, long ld, const float* mean, const float* inv_std, float* out, int Z, long P,
+                                 void* stream) {
+    UV_CHECK_ARG(mu && mean && inv_std && out && ld >= Z, "uv_vae_latent_out: bad arguments");
+    hipLaunchKernelGGL(latent_out_kernel, dim3((unsigned)min((P * Z + 255) / 256, (long)4096)), dim3(256), 0,
+                       (hipStream_t)stream, mu, ld, mean, inv_std, out, Z, P);
+    UV_CHECK_LAUNCH("uv_vae_latent_out");
+    return 0;
+}
+
+// encode entry: video [3, F, H, W] frames [f0, f0+T) -> patchified channels-last [T, H/2, W/2, ld]
+// channel = c*4 + r*2 + q  with q = row parity, r = column parity   ("b c f (h q) (w r) -> b (c r q) f h w")
+__global__ void video_in_kernel(const float* vid, float* out, long ld, int F, int H, int W, int f0, int T) {
+    const int Hp = H / 2, Wp = W / 2;
+    const long total = (long)T * Hp * Wp * 12;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % 12);
+        long r = i / 12;
+        const int w = (int)(r % Wp); r /= Wp;
+        const int h = (int)(r % Hp);
+        const int t = (int)(r / Hp);
+        const int c = ch >> 2, rr = (ch >> 1) & 1, q = ch & 1;
+        out[(((long)t * Hp + h) * Wp + w) * ld + ch] = vid[(((long)c * F + f0 + t) * H + 2 * h + q) * W + 2 * w + rr];
+    }
+}
+
+extern "C" int uv_vae_video_in(const float* vid, float* out, long ld, int F, int H, int W, int f0, int T, void* stream) {
+    UV_CHECK_ARG(vid && out && H % 2 == 0 && W % 2 == 0 && ld >= 12 && f0 >= 0 && f0 + T <= F, "uv_vae_video_in: bad arguments");
+    const long total = (long)T * (H / 2) * (W / 2) * 12;
+    hipLaunchKernelGGL(video_in_kernel, dim3((unsigned)min((total + 255) / 256, (long)4096)), dim3(256), 0,
+                       (hipStream_t)stream, vid, out, ld, F, H, W, f0, T);
+    UV_CHECK_LAUNCH("uv_vae_video_in");
+    return 0;
+}
+
+// decode exit: head output [T, Hp, Wp, ld] (12 channels) -> video [3, F, 2Hp, 2Wp] frames [f0, f0+T), clamped to
+// [-1, 1]   ("b (c r q) f h w -> b c f (h q) (w r)", vae2_2.py:306-312, clamp :1045)
+__global__ void video_out_kernel(const float* y, long ld, float* vid, int F, int Hp, int Wp, int f0, int T) {
+    const int H = 2 * Hp, W = 2 * Wp;
+    const long total = (long)3 * T * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        long r = i / W;
+        const int h = (int)(r % H); r /= H;
+        const int t = (int)(r % T);
+        const int c = (int)(r / T);
+        const int ch = c * 4 + (w & 1) * 2 + (h & 1);
+        const float v = y[(((long)t * Hp + (h >> 1)) * Wp + (w >> 1)) * ld + ch];
+        vid[(((long)c * F + f0 + t) * H + h) * W + w] = fminf(fmaxf(v, -1.0f), 1.0f);
+    }
+}
+
+extern "C" int uv_vae_video_out(const float* y, long ld, float* vid, int F, int Hp, int Wp, int f0, int T, void* stream) {
+    UV_CHECK_ARG(y && vid && ld >= 12 && f0 >= 0 && f0 + T <= F, "uv_vae_video_out: bad arguments");
+    const long total = (long)3 * T * 4 * Hp * Wp;
+    hipLaunchKernelGGL(video_out_kernel, dim3((unsigned)min((total + 255) / 256, (long)8192)), dim3(256), 0,
+                       (hipStream_t)stream, y, ld, vid, F, Hp, Wp, f0, T);
+    UV_CHECK_LAUNCH("uv_vae_video_out");
+    return 0;
+}

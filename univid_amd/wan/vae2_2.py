@@ -1,0 +1,468 @@
+"""Wan2.2 3D causal VAE (`Wan2_2_VAE`) on MI355X: the reference's module tree / state-dict names / list API over
+the fp32 implicit-GEMM convolution kernels of libunivid_hip.so.
+
+Mirrors /root/reference/models/wan/utils/modules/vae2_2.py: CausalConv3d :17-42, RMS_norm :45-59, Resample :71-190,
+ResidualBlock :193-235, AttentionBlock :238-277, AvgDown3D/DupUp3D :316-412, Down_/Up_ResidualBlock :415-497,
+Encoder3d :500-613, Decoder3d :616-723, WanVAE_ :734-860, Wan2_2_VAE :888-1051.
+
+The nn.Modules below only HOLD parameters (same names and shapes as the reference, so `Wan2.2_VAE.pth` loads);
+all arithmetic runs in `_Engine`, which walks the tree and launches HIP kernels on channels-last fp32 activations
+[T, H, W, C]. The reference's chunked streaming is kept exactly (encode: 1 + 4 + 4 ... frames, decode: one latent
+frame per chunk) because the first-chunk special cases ("Rep", DupUp3D(first_chunk)) are part of the function being
+computed; the per-convolution feature cache (CACHE_T = 2) becomes a 2-frame prefix of each convolution's input ring.
+Everything is fp32 like the reference (`dtype=torch.float`, vae2_2.py:897, 1028, 1042). No eager fallback.
+"""
+import logging
+import math
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+CACHE_T = 2
+
+_MEAN = [-0.2289, -0.0052, -0.1323, -0.2339, -0.2799, 0.0174, 0.1838, 0.1557, -0.1382, 0.0542, 0.2813, 0.0891, 0.1570,
+         -0.0098, 0.0375, -0.1825, -0.2246, -0.1207, -0.0698, 0.5109, 0.2665, -0.2108, -0.2158, 0.2502, -0.2055, -0.0322,
+         0.1109, 0.1567, -0.0729, 0.0899, -0.2799, -0.1230, -0.0313, -0.1649, 0.0117, 0.0723, -0.2839, -0.2083, -0.0520,
+         0.3748, 0.0152, 0.1957, 0.1433, -0.2944, 0.3573, -0.0548, -0.1681, -0.0667]
+_STD = [0.4765, 1.0364, 0.4514, 1.1677, 0.5313, 0.4990, 0.4818, 0.5013, 0.8158, 1.0344, 0.5894, 1.0901, 0.6885, 0.6165,
+        0.8454, 0.4978, 0.5759, 0.3523, 0.7135, 0.6804, 0.5833, 1.4146, 0.8986, 0.5659, 0.7069, 0.5338, 0.4889, 0.4917,
+        0.4069, 0.4999, 0.6866, 0.4093, 0.5709, 0.6065, 0.6415, 0.4944, 0.5726, 1.2042, 0.5458, 1.6887, 0.3971, 1.0600,
+        0.3943, 0.5537, 0.5444, 0.4089, 0.7468, 0.7744]
+
+
+# ---- parameter containers (names/shapes = reference) ------------------------------------------------------------
+class CausalConv3d(nn.Conv3d):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._padding = (self.padding[2], self.padding[2], self.padding[1], self.padding[1], 2 * self.padding[0], 0)
+        self.padding = (0, 0, 0)
+
+
+class RMS_norm(nn.Module):
+    def __init__(self, dim, channel_first=True, images=True, bias=False):
+        super().__init__()
+        broadcastable_dims = (1, 1, 1) if not images else (1, 1)
+        self.channel_first = channel_first
+        self.scale = dim ** 0.5
+        self.gamma = nn.Parameter(torch.ones((dim, *broadcastable_dims) if channel_first else (dim,)))
+        self.bias = 0.0
+
+
+class Resample(nn.Module):
+    def __init__(self, dim, mode):
+        assert mode in ("none", "upsample2d", "upsample3d", "downsample2d", "downsample3d")
+        super().__init__()
+        self.dim, self.mode = dim, mode
+        if mode in ("upsample2d", "upsample3d"):
+            self.resample = nn.Sequential(nn.Identity(), nn.Conv2d(dim, dim, 3, padding=1))
+            if mode == "upsample3d":
+                self.time_conv = CausalConv3d(dim, dim * 2, (3, 1, 1), padding=(1, 0, 0))
+        elif mode in ("downsample2d", "downsample3d"):
+            self.resample = nn.Sequential(nn.Identity(), nn.Conv2d(dim, dim, 3, stride=(2, 2)))
+            if mode == "downsample3d":
+                self.time_conv = CausalConv3d(dim, dim, (3, 1, 1), stride=(2, 1, 1), padding=(0, 0, 0))
+        else:
+            self.resample = nn.Identity()
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_dim, out_dim, dropout=0.0):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.residual = nn.Sequential(RMS_norm(in_dim, images=False), nn.SiLU(), CausalConv3d(in_dim, out_dim, 3, padding=1),
+                                      RMS_norm(out_dim, images=False), nn.SiLU(), nn.Dropout(dropout),
+                                      CausalConv3d(out_dim, out_dim, 3, padding=1))
+        self.shortcut = CausalConv3d(in_dim, out_dim, 1) if in_dim != out_dim else nn.Identity()
+
+
+class AttentionBlock(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.norm = RMS_norm(dim)
+        self.to_qkv = nn.Conv2d(dim, dim * 3, 1)
+        self.proj = nn.Conv2d(dim, dim, 1)
+
+
+class Down_ResidualBlock(nn.Module):
+    def __init__(self, in_dim, out_dim, dropout, mult, temperal_downsample=False, down_flag=False):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.factor_t = 2 if temperal_downsample else 1
+        self.factor_s = 2 if down_flag else 1
+        mods = []
+        for _ in range(mult):
+            mods.append(ResidualBlock(in_dim, out_dim, dropout))
+            in_dim = out_dim
+        if down_flag:
+            mods.append(Resample(out_dim, mode="downsample3d" if temperal_downsample else "downsample2d"))
+        self.downsamples = nn.Sequential(*mods)
+
+
+class Up_ResidualBlock(nn.Module):
+    def __init__(self, in_dim, out_dim, dropout, mult, temperal_upsample=False, up_flag=False):
+        super().__init__()
+        self.in_dim, self.out_dim, self.up_flag = in_dim, out_dim, up_flag
+        self.factor_t = 2 if temperal_upsample else 1
+        mods = []
+        for _ in range(mult):
+            mods.append(ResidualBlock(in_dim, out_dim, dropout))
+            in_dim = out_dim
+        if up_flag:
+            mods.append(Resample(out_dim, mode="upsample3d" if temperal_upsample else "upsample2d"))
+        self.upsamples = nn.Sequential(*mods)
+
+
+class Encoder3d(nn.Module):
+    def __init__(self, dim=128, z_dim=4, dim_mult=(1, 2, 4, 4), num_res_blocks=2, attn_scales=(),
+                 temperal_downsample=(True, True, False), dropout=0.0):
+        super().__init__()
+        dims = [dim * u for u in [1] + list(dim_mult)]
+        self.conv1 = CausalConv3d(12, dims[0], 3, padding=1)
+        downs = []
+        for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+            t_down = temperal_downsample[i] if i < len(temperal_downsample) else False
+            downs.append(Down_ResidualBlock(in_dim, out_dim, dropout, num_res_blocks, t_down, i != len(dim_mult) - 1))
+        self.downsamples = nn.Sequential(*downs)
+        self.middle = nn.Sequential(ResidualBlock(out_dim, out_dim, dropout), AttentionBlock(out_dim),
+                                    ResidualBlock(out_dim, out_dim, dropout))
+        self.head = nn.Sequential(RMS_norm(out_dim, images=False), nn.SiLU(), CausalConv3d(out_dim, z_dim, 3, padding=1))
+
+
+class Decoder3d(nn.Module):
+    def __init__(self, dim=128, z_dim=4, dim_mult=(1, 2, 4, 4), num_res_blocks=2, attn_scales=(),
+                 temperal_upsample=(False, True, True), dropout=0.0):
+        super().__init__()
+        dims = [dim * u for u in [dim_mult[-1]] + list(dim_mult[::-1])]
+        self.conv1 = CausalConv3d(z_dim, dims[0], 3, padding=1)
+        self.middle = nn.Sequential(ResidualBlock(dims[0], dims[0], dropout), AttentionBlock(dims[0]),
+                                    ResidualBlock(dims[0], dims[0], dropout))
+        ups = []
+        for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+            t_up = temperal_upsample[i] if i < len(temperal_upsample) else False
+            ups.append(Up_ResidualBlock(in_dim, out_dim, dropout, num_res_blocks + 1, t_up, i != len(dim_mult) - 1))
+        self.upsamples = nn.Sequential(*ups)
+        self.head = nn.Sequential(RMS_norm(out_dim, images=False), nn.SiLU(), CausalConv3d(out_dim, 12, 3, padding=1))
+
+
+# ---- execution engine -----------------------------------------------------------------------------------------
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+class _ConvOp:
+    """One convolution: channels-last weight [Cout, taps * Cin_pad] and its input ring."""
+
+    def __init__(self, conv, is2d=False):
+        w = conv.weight.detach().float()
+        if is2d:
+            w = w.unsqueeze(2)
+        self.cout, self.cin, self.kt, self.kh, self.kw = w.shape
+        self.cin_pad = _pad32(self.cin)
+        wp = torch.zeros(self.cout, self.kt, self.kh, self.kw, self.cin_pad, dtype=torch.float32, device=w.device)
+        wp[..., :self.cin] = w.permute(0, 2, 3, 4, 1)
+        self.w = wp.reshape(self.cout, -1).contiguous()
+        self.w2d = w.reshape(self.cout, self.cin).contiguous() if (self.kt, self.kh, self.kw) == (1, 1, 1) else None
+        self.b = conv.bias.detach().float().contiguous()
+        self.rings = {}
+
+    def ring(self, H, W, tmax, prefix=CACHE_T):
+        key = (H, W, tmax, prefix)
+        r = self.rings.get(key)
+        if r is None:
+            r = torch.zeros(prefix + tmax, H, W, self.cin_pad, dtype=torch.float32, device=self.w.device)
+            self.rings[key] = r
+        return r
+
+
+def _shift(ring, T, prefix=CACHE_T):
+    """cache <- last `prefix` frames of [cache | current T frames] (vae2_2.py:219-232 feature-cache update)."""
+    tail = ring[T:T + prefix]
+    ring[:prefix].copy_(tail.clone() if T < prefix else tail)
+
+
+class _Engine:
+    def __init__(self, model: "WanVAE_"):
+        self.m = model
+        self.ops = {}
+        for name, mod in model.named_modules():
+            if isinstance(mod, nn.Conv3d):
+                self.ops[mod] = _ConvOp(mod)
+            elif isinstance(mod, nn.Conv2d):
+                self.ops[mod] = _ConvOp(mod, is2d=True)
+        self.dev = next(model.parameters()).device
+
+    def reset(self):
+        """WanVAE_.clear_cache (vae2_2.py:853-860): all cached frames back to the causal zero padding."""
+        for op in self.ops.values():
+            for r in op.rings.values():
+                r.zero_()
+
+    # -- kernels --
+    def _conv(self, op, src, Tin, Hin, Win, Tout, Hout, Wout, st=1, sh=1, sw=1, t_off=0, ph=0, pw=0, up=0, interleave=0,
+              resid=None, out=None, ldo=None):
+        cout = op.cout // 2 if interleave else op.cout
+        tt = Tout * 2 if interleave else Tout
+        if out is None:
+            out = torch.empty(tt, Hout, Wout, cout, dtype=torch.float32, device=self.dev)
+            ldo = cout
+        _lib.call("uv_conv3d_f32", _lib.ptr(src), src.stride(-2), Tin, Hin, Win, _lib.ptr(op.w), _lib.ptr(op.b), _lib.ptr(out),
+                  ldo, Tout, Hout, Wout, op.cin_pad, op.cout, op.kt, op.kh, op.kw, st, sh, sw, t_off, ph, pw, up, interleave,
+                  _lib.ptr(resid), 0 if resid is None else resid.stride(-2), _lib.stream_ptr(),
+                  flops=2 * Tout * Hout * Wout * op.cout * op.kt * op.kh * op.kw * op.cin)
+        return out
+
+    def _rms_silu(self, x, gamma, out, silu=True):
+        P = x.numel() // x.shape[-1]
+        _lib.call("uv_vae_rms_silu", _lib.ptr(x), x.stride(-2), _lib.ptr(gamma), _lib.ptr(out), out.stride(-2), P, x.shape[-1],
+                  int(silu), _lib.stream_ptr())
+
+    def _pointwise(self, op, x, resid=None):
+        """1x1(x1) convolution = fp32 GEMM over pixel rows."""
+        P = x.numel() // x.shape[-1]
+        out = torch.empty(*x.shape[:-1], op.cout, dtype=torch.float32, device=self.dev)
+        _lib.call("uv_gemm_f32_nt", _lib.ptr(x), x.stride(-2), _lib.ptr(op.w2d), op.w2d.stride(0), _lib.ptr(op.b), P, op.cout,
+                  op.cin, _lib.ptr(out), op.cout, _lib.ptr(resid), 0 if resid is None else resid.stride(-2), _lib.stream_ptr())
+        return out
+
+    # -- blocks --
+    def causal_conv(self, conv, x_into_ring, T, H, W, tmax, resid=None):
+        """3x3x3 causal conv over the ring [cache(2) | T frames]; `x_into_ring(dst)` fills the current frames."""
+        op = self.ops[conv]
+        ring = op.ring(H, W, tmax)
+        x_into_ring(ring[CACHE_T:CACHE_T + T])
+        y = self._conv(op, ring, CACHE_T + T, H, W, T, H, W, t_off=0, ph=1, pw=1, resid=resid)
+        _shift(ring, T)
+        return y
+
+    def resblock(self, blk, x, tmax):
+        """ResidualBlock.forward vae2_2.py:214-235."""
+        T, H, W, C = x.shape
+        res = blk.residual
+        h = x if isinstance(blk.shortcut, nn.Identity) else self._pointwise(self.ops[blk.shortcut], x)
+        y = self.causal_conv(res[2], lambda dst: self._rms_silu(x, res[0].gamma, dst), T, H, W, tmax)
+        return self.causal_conv(res[6], lambda dst: self._rms_silu(y, res[3].gamma, dst), T, H, W, tmax, resid=h)
+
+    def attention(self, blk, x):
+        """AttentionBlock.forward vae2_2.py:255-277: per-frame single-head attention, head_dim = C, fp32."""
+        T, H, W, C = x.shape
+        n = H * W
+        n4 = (n + 3) // 4 * 4
+        out = torch.empty_like(x)
+        xn = torch.zeros(n4, C, dtype=torch.float32, device=self.dev)            # rows >= n stay zero (GEMM N/K padding)
+        qkv_op, proj_op = self.ops[blk.to_qkv], self.ops[blk.proj]
+        sp = _lib.stream_ptr
+        for t in range(T):
+            xt = x[t].reshape(n, C)
+            self._rms_silu(xt, blk.norm.gamma, xn[:n], silu=False)
+            qkv = self._pointwise(qkv_op, xn)                                   # [n4, 3C]
+            q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+            s = torch.empty(n, n4, dtype=torch.float32, device=self.dev)
+            _lib.call("uv_gemm_f32_nt", _lib.ptr(q), q.stride(0), _lib.ptr(k), k.stride(0), None, n, n4, C, _lib.ptr(s), n4, None, 0, sp())
+            _lib.call("uv_softmax_rows_f32", _lib.ptr(s), n4, n, n, 1.0 / math.sqrt(C), sp())
+            if n4 > n:
+                s[:, n:].zero_()
+            vt = torch.zeros(C, n4, dtype=torch.float32, device=self.dev)
+            vt[:, :n] = v[:n].t()
+            o = torch.empty(n, C, dtype=torch.float32, device=self.dev)
+            _lib.call("uv_gemm_f32_nt", _lib.ptr(s), n4, _lib.ptr(vt), n4, None, n, C, n4, _lib.ptr(o), C, None, 0, sp())
+            ot = out[t].reshape(n, C)
+            _lib.call("uv_gemm_f32_nt", _lib.ptr(o), C, _lib.ptr(proj_op.w2d), C, _lib.ptr(proj_op.b), n, C, C, _lib.ptr(ot), C,
+                      _lib.ptr(xt), C, sp())
+        return out
+
+    def upsample(self, rs, x, first_chunk, tmax):
+        """Resample.forward (upsample2d / upsample3d) vae2_2.py:112-155."""
+        T, H, W, C = x.shape
+        if rs.mode == "upsample3d" and not first_chunk:
+            op = self.ops[rs.time_conv]
+            ring = op.ring(H, W, tmax)
+            ring[CACHE_T:CACHE_T + T].copy_(x)
+            x = self._conv(op, ring, CACHE_T + T, H, W, T, H, W, t_off=0, interleave=1)
+            _shift(ring, T)
+            T = 2 * T
+        # first chunk of upsample3d: the "Rep" sentinel - no time conv, cache stays at the zero padding
+        return self._conv(self.ops[rs.resample[1]], x, T, H, W, T, 2 * H, 2 * W, ph=1, pw=1, up=1)
+
+    def downsample(self, rs, x, first_chunk, tmax):
+        """Resample.forward (downsample2d / downsample3d) vae2_2.py:153-169."""
+        T, H, W, C = x.shape
+        y = self._conv(self.ops[rs.resample[1]], x, T, H, W, T, H // 2, W // 2, sh=2, sw=2)
+        if rs.mode == "downsample3d":
+            op = self.ops[rs.time_conv]
+            ring = op.ring(H // 2, W // 2, tmax, prefix=1)
+            if first_chunk:
+                ring[0].copy_(y[-1])                      # feat_cache[idx] = x.clone(); x passes through
+            else:
+                ring[1:1 + T].copy_(y)
+                tout = (1 + T - 3) // 2 + 1
+                last = y[-1].clone()
+                y = self._conv(op, ring, 1 + T, H // 2, W // 2, tout, H // 2, W // 2, st=2, t_off=0)
+                ring[0].copy_(last)
+        return y
+
+    # -- encoder / decoder bodies --
+    def encoder_chunk(self, vid, f0, T, first_chunk, tmax):
+        enc = self.m.encoder
+        F, Hv, Wv = vid.shape[1:]
+        H, W = Hv // 2, Wv // 2
+
+        def fill(dst):
+            _lib.call("uv_vae_video_in", _lib.ptr(vid), _lib.ptr(dst), dst.stride(-2), F, Hv, Wv, f0, T, _lib.stream_ptr())
+
+        x = self.causal_conv(enc.conv1, fill, T, H, W, tmax)
+        for stage in enc.downsamples:
+            x_copy = x
+            for mod in stage.downsamples:
+                x = self.resblock(mod, x, tmax) if isinstance(mod, ResidualBlock) else self.downsample(mod, x, first_chunk, tmax)
+            Tc, Hc, Wc, Cc = x_copy.shape
+            _lib.call("uv_vae_avgdown_add", _lib.ptr(x_copy), _lib.ptr(x), Tc, Hc, Wc, Cc, stage.out_dim, stage.factor_t,
+                      stage.factor_s, _lib.stream_ptr())
+        x = self.resblock(enc.middle[0], x, tmax)
+        x = self.attention(enc.middle[1], x)
+        x = self.resblock(enc.middle[2], x, tmax)
+        T2, H2, W2, _ = x.shape
+        return self.causal_conv(enc.head[2], lambda dst: self._rms_silu(x, enc.head[0].gamma, dst), T2, H2, W2, tmax)
+
+    def decoder_chunk(self, xin, first_chunk):
+        """xin: [1, h, w, z] rows of conv2's output for one latent frame -> [T, 8h, 8w, 12]."""
+        dec = self.m.decoder
+        _, H, W, _ = xin.shape
+        x = self.causal_conv(dec.conv1, lambda dst: dst[..., :xin.shape[-1]].copy_(xin), 1, H, W, 1)
+        x = self.resblock(dec.middle[0], x, 1)
+        x = self.attention(dec.middle[1], x)
+        x = self.resblock(dec.middle[2], x, 1)
+        tmax = 1
+        for stage in dec.upsamples:
+            xm = x
+            for mod in stage.upsamples:
+                if isinstance(mod, ResidualBlock):
+                    xm = self.resblock(mod, xm, tmax)
+                else:
+                    xm = self.upsample(mod, xm, first_chunk, tmax)
+            if stage.up_flag:
+                T, Hh, Ww, C = x.shape
+                ft = stage.factor_t
+                _lib.call("uv_vae_dupup_add", _lib.ptr(x), _lib.ptr(xm), T, Hh, Ww, C, stage.out_dim, ft,
+                          (ft - 1) if first_chunk else 0, _lib.stream_ptr())
+                tmax *= ft
+            x = xm
+        T, Hh, Ww, _ = x.shape
+        return self.causal_conv(dec.head[2], lambda dst: self._rms_silu(x, dec.head[0].gamma, dst), T, Hh, Ww, tmax)
+
+
+class WanVAE_(nn.Module):
+    def __init__(self, dim=160, dec_dim=256, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, attn_scales=(),
+                 temperal_downsample=(True, True, False), dropout=0.0):
+        super().__init__()
+        self.dim, self.z_dim, self.dim_mult = dim, z_dim, list(dim_mult)
+        self.num_res_blocks = num_res_blocks
+        self.temperal_downsample = list(temperal_downsample)
+        self.temperal_upsample = self.temperal_downsample[::-1]
+        self.encoder = Encoder3d(dim, z_dim * 2, dim_mult, num_res_blocks, attn_scales, self.temperal_downsample, dropout)
+        self.conv1 = CausalConv3d(z_dim * 2, z_dim * 2, 1)
+        self.conv2 = CausalConv3d(z_dim, z_dim, 1)
+        self.decoder = Decoder3d(dec_dim, z_dim, dim_mult, num_res_blocks, attn_scales, self.temperal_upsample, dropout)
+        self._engine = None
+        self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
+
+    def invalidate(self):
+        self._engine = None
+
+    def prepare(self):
+        if next(self.parameters()).device.type != "cuda":
+            raise _lib.UnividHipError("WanVAE_.prepare: parameters must be on the GPU - there is no CPU path in univid_amd")
+        _lib.init()
+        self._engine = _Engine(self)
+        return self
+
+    def _eng(self):
+        if self._engine is None:
+            self.prepare()
+        return self._engine
+
+    def clear_cache(self):
+        if self._engine is not None:
+            self._engine.reset()
+
+    def encode(self, x, scale):
+        """WanVAE_.encode vae2_2.py:783-810: x [1, 3, F, H, W] fp32 -> [1, z, (F-1)//4+1, H/16, W/16]."""
+        eng = self._eng()
+        eng.reset()
+        vid = x[0].contiguous().float()
+        F = vid.shape[1]
+        outs = []
+        for i in range(1 + (F - 1) // 4):
+            f0, T = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4)
+            outs.append(eng.encoder_chunk(vid, f0, T, first_chunk=(i == 0), tmax=4))
+        out = torch.cat(outs, 0)                                                  # [f, h, w, 2z]
+        y = eng._pointwise(eng.ops[self.conv1], out)                              # 1x1x1, then chunk(2) -> mu
+        f, h, w, _ = y.shape
+        mu = torch.empty(1, self.z_dim, f, h, w, dtype=torch.float32, device=y.device)
+        _lib.call("uv_vae_latent_out", _lib.ptr(y), y.stride(-2), _lib.ptr(scale[0]), _lib.ptr(scale[1]), _lib.ptr(mu), self.z_dim,
+                  f * h * w, _lib.stream_ptr())
+        eng.reset()
+        return mu
+
+    def decode(self, z, scale, clamp=True):
+        """WanVAE_.decode vae2_2.py:812-839 (+ the wrapper's clamp :1045): z [1, z, f, h, w] -> [1, 3, 4(f-1)+1, 16h, 16w]."""
+        eng = self._eng()
+        eng.reset()
+        zz = z[0].contiguous().float()
+        Z, f, h, w = zz.shape
+        rows = torch.empty(f, h, w, Z, dtype=torch.float32, device=zz.device)
+        _lib.call("uv_vae_latent_in", _lib.ptr(zz), _lib.ptr(scale[0]), _lib.ptr(scale[1]), _lib.ptr(rows), Z, Z, f * h * w,
+                  _lib.stream_ptr())
+        x = eng._pointwise(eng.ops[self.conv2], rows)                             # conv2 (1x1x1) on all frames
+        F = 4 * (f - 1) + 1
+        vid = torch.empty(1, 3, F, 16 * h, 16 * w, dtype=torch.float32, device=zz.device)
+        f0 = 0
+        for i in range(f):
+            y = eng.decoder_chunk(x[i:i + 1], first_chunk=(i == 0))              # [T, 8h, 8w, 12]
+            T = y.shape[0]
+            _lib.call("uv_vae_video_out", _lib.ptr(y), y.stride(-2), _lib.ptr(vid), F, 8 * h, 8 * w, f0, T, _lib.stream_ptr())
+            f0 += T
+        assert f0 == F
+        eng.reset()
+        return vid
+
+    def init_weights(self, seed=0):
+        from .. import detinit
+        detinit.init_module_(self, seed)
+        self.invalidate()
+        return self
+
+
+class Wan2_2_VAE:
+    """List-API wrapper (vae2_2.py:888-1051). `vae_pth=None` builds a randomly initialised model (offline use);
+    a path loads the reference checkpoint (same state-dict keys)."""
+
+    def __init__(self, z_dim=48, c_dim=160, vae_pth=None, dim_mult=(1, 2, 4, 4), temperal_downsample=(False, True, True),
+                 dtype=torch.float, device="cuda", dec_dim=256, seed=0):
+        self.dtype = dtype
+        self.device = torch.device(device)
+        mean = torch.tensor(_MEAN, dtype=dtype, device=device)
+        std = torch.tensor(_STD, dtype=dtype, device=device)
+        self.scale = [mean, 1.0 / std]
+        with torch.device(device):
+            model = WanVAE_(dim=c_dim, dec_dim=dec_dim, z_dim=z_dim, dim_mult=dim_mult, num_res_blocks=2, attn_scales=[],
+                            temperal_downsample=temperal_downsample, dropout=0.0)
+        if vae_pth is not None:
+            logging.info(f"loading {vae_pth}")
+            model.load_state_dict(torch.load(vae_pth, map_location=device))
+        else:
+            model.init_weights(seed)
+        self.model = model.eval().requires_grad_(False).to(device)
+
+    def encode(self, videos):
+        if not isinstance(videos, list):
+            raise TypeError("videos should be a list")
+        return [self.model.encode(u.to(self.device).unsqueeze(0), self.scale).float().squeeze(0) for u in videos]
+
+    def decode(self, zs):
+        if not isinstance(zs, list):
+            raise TypeError("zs should be a list")
+        return [self.model.decode(u.to(self.device).unsqueeze(0), self.scale).float().squeeze(0) for u in zs]
