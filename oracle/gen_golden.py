@@ -1,0 +1,260 @@
+"""TEST INFRASTRUCTURE ONLY. Generates tests/golden/*.npz by IMPORTING THE REFERENCE (build container only).
+
+    python -m oracle.gen_golden            # needs /root/reference; rewrites tests/golden/
+
+The reference ships no tests or golden vectors for this path, so the pins are made here:
+every fixture holds INPUTS and the REFERENCE MODULES' OUTPUTS (run on CPU through the shims of
+oracle/_refimport.py), and while generating, the CPU restatement in oracle/ is asserted bit-identical to the
+reference on the same inputs. Weights are never stored: both sides derive them from univid_amd.detinit
+(seed in the fixture). bf16 tensors are stored as their uint16 bit patterns.
+"""
+import ast
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import _refimport, sampler, unipc, wan_dit, wan_vae  # noqa: E402
+from univid_amd import detinit  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _np(t):
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().view(np.uint16)
+    return t.detach().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (_np(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"  wrote {path} ({os.path.getsize(path) >> 10} KiB)")
+
+
+def ref_dit(ns, cfg, seed):
+    m = ns.model.WanModel(model_type="ti2v", patch_size=cfg["patch_size"], text_len=cfg["text_len"], in_dim=cfg["in_dim"],
+                          dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], freq_dim=cfg["freq_dim"], text_dim=cfg["text_dim"],
+                          out_dim=cfg["out_dim"], num_heads=cfg["num_heads"], num_layers=cfg["num_layers"]).eval()
+    detinit.init_module_(m, seed=seed)
+    return m
+
+
+def gen_dit_tiny(ns):
+    print("dit_tiny")
+    cfg = wan_dit.TINY_CFG
+    m = ref_dit(ns, cfg, 0)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(48, 4, 16, 16, generator=g)
+    ctx = torch.randn(20, cfg["text_dim"], generator=g)
+    L = 4 * 8 * 8
+    t_one = torch.full((1, L), 937.0)
+    t_two = t_one.clone()
+    t_two[0, :64] = 0.0                                # i2v: first latent frame at timestep 0 (textimage2video.py:573)
+    outs = {}
+    for name, t in (("one", t_one), ("two", t_two)):
+        with torch.no_grad(), torch.amp.autocast("cuda", dtype=torch.bfloat16):
+            ref = m([x], t=t, context=[ctx], seq_len=L)[0]
+        with torch.no_grad():
+            mine = wan_dit.dit_forward(sd, cfg, [x], t, [ctx], L)[0]
+        assert torch.equal(ref, mine), "oracle restatement != reference (dit_tiny)"
+        outs[name] = ref
+    # padded sequence: seq_len > L (padding tokens must not change the valid outputs)
+    with torch.no_grad(), torch.amp.autocast("cuda", dtype=torch.bfloat16):
+        ref_pad = m([x], t=torch.full((1, L + 32), 937.0), context=[ctx], seq_len=L + 32)[0]
+    save("dit_tiny", seed=0, x=x, ctx=ctx, t_one=t_one, t_two=t_two, out_one=outs["one"], out_two=outs["two"], out_pad=ref_pad)
+
+
+def gen_dit_block_3072(ns):
+    """One TI2V-5B-width block (dim 3072, ffn 14336, 24 heads) at L = 2*4*6 = 48 tokens, text_len 64."""
+    print("dit_block_3072")
+    dim, ffn, heads, L, Lc = 3072, 14336, 24, 48, 64
+    blk = ns.model.WanAttentionBlock(dim, ffn, heads, (-1, -1), True, True, 1e-6).eval()
+    sd_named = {"blocks.0." + k: v for k, v in blk.state_dict(keep_vars=True).items()}
+    detinit.init_state_dict_(sd_named, seed=7)
+    sd = {k: v.detach().clone() for k, v in sd_named.items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, L, dim, generator=g)
+    e_rows = torch.randn(2, 6, dim, generator=g) * 0.3
+    tid = (torch.arange(L) >= 24).long()
+    e0 = e_rows[tid].unsqueeze(0)
+    ctx = (torch.randn(1, Lc, dim, generator=g) * 0.5).to(torch.bfloat16)
+    grid = torch.tensor([[2, 4, 6]])
+    freqs = wan_dit.rope_table(dim // heads)
+    seq_lens = torch.tensor([L])
+    outs = {}
+    for name, xin in (("f32", x), ("bf16", x.to(torch.bfloat16))):     # bf16 = what block 0 sees (patch embedding output)
+        with torch.no_grad(), torch.amp.autocast("cuda", dtype=torch.bfloat16):
+            ref = blk(xin, e0, seq_lens, grid, freqs, ctx, None)
+        with torch.no_grad():
+            mine = wan_dit.block_forward(sd, "blocks.0.", xin, e0, seq_lens, grid, freqs, ctx, heads, 1e-6)
+        assert ref.dtype == torch.float32 and torch.equal(ref, mine), "oracle restatement != reference (block)"
+        outs[name] = ref
+    save("dit_block_3072", seed=7, x=x, e_rows=e_rows, tid=tid, ctx=ctx, grid=grid, out_f32=outs["f32"], out_bf16=outs["bf16"])
+
+
+def gen_unipc(ns):
+    print("unipc")
+    S = ns.unipc.FlowUniPCMultistepScheduler
+    arrs = {}
+    for steps, shift in ((50, 5.0), (10, 5.0), (40, 3.0)):
+        sch = S(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        sch.set_timesteps(steps, device="cpu", shift=shift)
+        mine = unipc.FlowUniPC(1000, shift=1)
+        ts = mine.set_timesteps(steps, shift=shift)
+        assert torch.equal(ts, sch.timesteps) and torch.equal(mine.sigmas, sch.sigmas)
+        arrs[f"timesteps_{steps}_{shift}"] = sch.timesteps
+        arrs[f"sigmas_{steps}_{shift}"] = sch.sigmas
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 48, 2, 6, 8, generator=g)
+    outs = torch.randn(10, 1, 48, 2, 6, 8, generator=g)
+    sch = S(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    sch.set_timesteps(10, device="cpu", shift=5.0)
+    mine = unipc.FlowUniPC(1000, shift=1)
+    mine.set_timesteps(10, shift=5.0)
+    lat, latm, traj = x, x, []
+    for i, t in enumerate(sch.timesteps):
+        with torch.amp.autocast("cuda", dtype=torch.bfloat16):
+            lat = sch.step(outs[i], t, lat, return_dict=False)[0]
+        latm = mine.step(outs[i], t, latm)
+        assert torch.equal(lat, latm), f"oracle UniPC != reference at step {i}"
+        traj.append(lat)
+    save("unipc", x=x, model_outputs=outs, trajectory=torch.stack(traj), **arrs)
+
+
+def gen_sampler(ns):
+    print("sampler_tiny")
+    cfg = wan_dit.TINY_CFG
+    m = ref_dit(ns, cfg, 0)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(42)
+    noise = torch.randn(48, 4, 16, 16, generator=g)
+    ctx = torch.randn(20, cfg["text_dim"], generator=g)
+    ctxn = torch.randn(7, cfg["text_dim"], generator=g)
+    z = torch.randn(48, 1, 16, 16, generator=g)
+    steps, shift, gs = 10, 5.0, 5.0
+    S = ns.unipc.FlowUniPCMultistepScheduler
+    arrs = {}
+    for mode in ("t2v", "i2v"):
+        i2v = mode == "i2v"
+        rec_ref = []
+        # composition of the reference pieces exactly as textimage2video.py:329-394 / 521-601 orders them
+        with torch.amp.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+            sch = S(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+            sch.set_timesteps(steps, device="cpu", shift=shift)
+            latent = noise
+            _, mask2 = _refimport.ref_masks_like([noise], zero=i2v)
+            if i2v:
+                latent = (1. - mask2[0]) * z + mask2[0] * latent
+            seq_len = 4 * 8 * 8
+            for t in sch.timesteps:
+                timestep = torch.stack([t])
+                temp_ts = (mask2[0][0][:, ::2, ::2] * timestep).flatten()
+                temp_ts = torch.cat([temp_ts, temp_ts.new_ones(seq_len - temp_ts.size(0)) * timestep])
+                timestep = temp_ts.unsqueeze(0)
+                c = m([latent], t=timestep, context=[ctx], seq_len=seq_len)[0]
+                u = m([latent], t=timestep, context=[ctxn], seq_len=seq_len)[0]
+                npred = u + gs * (c - u)
+                latent = sch.step(npred.unsqueeze(0), t, latent.unsqueeze(0), return_dict=False)[0].squeeze(0)
+                if i2v:
+                    latent = (1. - mask2[0]) * z + mask2[0] * latent
+                rec_ref.append((npred, latent))
+        rec = []
+        with torch.no_grad():
+            mine = sampler.denoise(sd, cfg, noise, [ctx], [ctxn], steps, shift, gs, z=(z if i2v else None), record=rec)
+        for (a, b), (c_, d) in zip(rec_ref, rec):
+            assert torch.equal(a, c_) and torch.equal(b, d), "oracle sampler != reference"
+        keep = [0, 1, 2, 5, 9]                                      # per-step tensors kept (all were checked above)
+        arrs[f"{mode}_noise_pred"] = torch.stack([rec_ref[i][0] for i in keep])
+        arrs[f"{mode}_latents"] = torch.stack([rec_ref[i][1] for i in keep])
+        arrs["kept_steps"] = torch.tensor(keep)
+    save("sampler_tiny", seed=0, steps=steps, shift=shift, guide_scale=gs, noise=noise, ctx=ctx, ctx_null=ctxn, z=z, **arrs)
+
+
+def gen_vae(ns):
+    print("vae_small")
+    cfg = wan_vae.SMALL_CFG
+    m = ns.vae.WanVAE_(dim=cfg["dim"], dec_dim=cfg["dec_dim"], z_dim=cfg["z_dim"], dim_mult=cfg["dim_mult"], num_res_blocks=2,
+                       attn_scales=[], temperal_downsample=cfg["temperal_downsample"], dropout=0.0).eval()
+    detinit.init_module_(m, seed=1)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    v = wan_vae.WanVAE(sd, cfg)
+    scale = wan_vae.scale_tensors()
+    g = torch.Generator().manual_seed(3)
+    arrs = {}
+    for i, shape in enumerate([(3, 9, 32, 48), (3, 1, 32, 32), (3, 5, 48, 32)]):
+        vid = torch.tanh(torch.randn(*shape, generator=g))
+        with torch.no_grad():
+            ref = m.encode(vid.unsqueeze(0), scale)
+            mine = v.encode(vid.unsqueeze(0), scale)
+        assert torch.equal(ref, mine), "oracle VAE encode != reference"
+        arrs[f"enc_in_{i}"], arrs[f"enc_out_{i}"] = vid, ref[0]
+    for i, shape in enumerate([(48, 3, 2, 3), (48, 1, 2, 2), (48, 2, 3, 2)]):
+        z = torch.randn(*shape, generator=g)
+        with torch.no_grad():
+            ref = m.decode(z.unsqueeze(0), scale).float().clamp_(-1, 1)      # + the wrapper's clamp (vae2_2.py:1045)
+            mine = v.decode(z.unsqueeze(0), scale).clamp(-1, 1)
+        assert torch.equal(ref, mine), "oracle VAE decode != reference"
+        arrs[f"dec_in_{i}"], arrs[f"dec_out_{i}"] = z, ref[0]
+    save("vae_small", seed=1, **arrs)
+
+
+def gen_text_weight():
+    """Known-answer table of Wan22ContextWrapper._calculate_text_weight (models/model_pipeline.py:1699-1735): only
+    that method's source is compiled (model_pipeline.py cannot be imported: pip install + file writes at import)."""
+    print("text_weight")
+    src = open(os.path.join(_refimport.REF_ROOT, "models", "model_pipeline.py")).read()
+    tree = ast.parse(src)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Wan22ContextWrapper"][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "_calculate_text_weight"][0]
+    nsx = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "model_pipeline.py:_calculate_text_weight", "exec"), nsx)
+    rows = []
+    for schedule in ("cosine", "linear", "exponential", "other"):
+        for total, ratio in ((50, 0.4), (10, 0.4), (30, 0.25), (1, 0.4)):
+            for enabled in (True, False):
+                cfg = types.SimpleNamespace(use_dynamic_text_weight=enabled, total_sampling_steps=total,
+                                            text_weight_transition_ratio=ratio, text_weight_min=1.0, text_weight_max=1.3,
+                                            text_weight_schedule=schedule)
+                self_ = types.SimpleNamespace(config=cfg)
+                for step in range(0, 2 * total + 1):
+                    w = nsx["_calculate_text_weight"](self_, step)
+                    mine = sampler.text_weight(step, total, ratio, 1.3, 1.0, schedule, enabled)
+                    assert w == mine, (schedule, total, ratio, enabled, step, w, mine)
+                    rows.append([schedule, total, ratio, int(enabled), step, w])
+    with open(os.path.join(OUT, "text_weight.json"), "w") as f:
+        json.dump({"columns": ["schedule", "total_steps", "ratio", "enabled", "forward_call", "weight"], "rows": rows}, f)
+    print(f"  wrote text_weight.json ({len(rows)} rows)")
+
+
+def gen_masks():
+    print("masks_like")
+    x = [torch.zeros(3, 4, 2, 2)]
+    a1, a2 = _refimport.ref_masks_like(x, zero=False)
+    b1, b2 = _refimport.ref_masks_like(x, zero=True)
+    m1, m2 = sampler.masks_like(x, zero=True)
+    assert torch.equal(b1[0], m1[0]) and torch.equal(b2[0], m2[0])
+    save("masks_like", ones1=a1[0], ones2=a2[0], zero1=b1[0], zero2=b2[0])
+
+
+def main():
+    assert _refimport.available(), "the reference is not mounted; fixtures can only be generated in the build container"
+    os.makedirs(OUT, exist_ok=True)
+    ns = _refimport.load_reference()
+    torch.set_num_threads(8)
+    only = sys.argv[1:]
+    gens = {"unipc": lambda: gen_unipc(ns), "masks": gen_masks, "text_weight": gen_text_weight, "dit_tiny": lambda: gen_dit_tiny(ns),
+            "sampler": lambda: gen_sampler(ns), "vae": lambda: gen_vae(ns), "block": lambda: gen_dit_block_3072(ns)}
+    for k, fn in gens.items():
+        if not only or k in only:
+            fn()
+
+
+if __name__ == "__main__":
+    main()

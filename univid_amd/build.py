@@ -15,7 +15,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libunivid_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value", "-DNDEBUG"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value", "-DNDEBUG",
+         # no implicit FMA contraction: a*b+c keeps the two roundings PyTorch eager has (explicit fmaf/MFMA are unaffected)
+         "-ffp-contract=off"]
 
 
 def _hipcc():

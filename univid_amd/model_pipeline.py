@@ -1,0 +1,237 @@
+"""UniVid's fusion-pipeline API surface over the MI355X hot path.
+
+Mirrors the parts of /root/reference/models/model_pipeline.py that sit directly on the denoise path:
+  * CrossAttentionConfig (:154-296)        - same field names and defaults (the fields inference.py:145-194 passes)
+  * Wan22ContextWrapper (:1624-1900)       - per-layer cross-attention hook = dynamic text-weight schedule
+                                             (:1699-1810) and the DiT-forward step counter (:1844-1886)
+  * CrossAttentionFusionPipeline (:2110-)  - generate_video_with_bagel_context(text, image, steps=, guidance_scale=,
+                                             frames=, size=, shift=, seed=) -> (video | None, path | None) (:2577-2655)
+so that inference.py can drive this package unchanged. Everything off the hot path is pluggable instead of
+re-built (SURVEY.md section 2 marks it out of scope): the BAGEL-7B semantic extractor, the ContextProjector adapter,
+the umT5 text encoder, LoRA, training and video file I/O are callables/objects the caller supplies.
+
+Behaviour kept on purpose: the text-encoder override of the reference is dead code (Python resolves
+`obj(...)` through the type), so the DiT receives the text encoder's embeddings; the per-layer forward hook IS live
+and rescales the first min(bagel_sequence_length, text_len // 2) rows of the embedded context by w(step), where
+`step` counts DiT FORWARD calls (2 per sampler step).
+"""
+import logging
+import math
+import os
+import time
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+from .wan.textimage2video import TI2VConfig, WanTI2V
+
+
+@dataclass
+class CrossAttentionConfig:
+    bagel_model_path: str = os.getenv("BAGEL_MODEL_PATH", "your_bagel_model_path_here")
+    wan_model_path: str = os.getenv("WAN_MODEL_PATH", "your_wan_model_path_here")
+    bagel_gpu: int = 0
+    wan_gpu: int = 1
+    cross_attn_gpu: int = 2
+    backup_gpu: int = 3
+    fusion_mode: str = "context_replacement"
+    enable_bagel_extraction: bool = True
+    enable_wan_injection: bool = True
+    bagel_sequence_length: int = 128
+    wan_text_length: int = 512
+    bagel_hidden_dim: int = 3584
+    wan_text_dim: int = 4096
+    use_lora: bool = True
+    lora_rank: int = 8
+    lora_alpha: int = 16
+    lora_dropout: float = 0.1
+    lora_target_strategy: str = "your_method_here"
+    guidance_strength: float = 1.0
+    bagel_cross_attn_layers: List[int] = None
+    freeze_bagel: bool = True
+    freeze_wan_vae: bool = True
+    freeze_t5: bool = True
+    skip_t5_loading: bool = True
+    train_wan_dit: bool = True
+    train_cross_attn: bool = True
+    use_dynamic_text_weight: bool = True
+    text_weight_max: float = 1.3
+    text_weight_min: float = 1.0
+    text_weight_schedule: str = "cosine"
+    text_weight_transition_ratio: float = 0.4
+    total_sampling_steps: int = 25
+    use_bfloat16: bool = True
+    enable_autocast: bool = True
+    video_length: int = 121
+    video_size: Tuple[int, int] = (1280, 704)
+    video_fps: int = 8
+    output_dir: str = "./cross_attention_outputs"
+    save_video_mp4: bool = True
+    save_tensor_backup: bool = True
+
+    def __post_init__(self):
+        if self.bagel_cross_attn_layers is None:
+            self.bagel_cross_attn_layers = [8, 15, 22, 28]
+
+
+class Wan22ContextWrapper:
+    """model_pipeline.py:1624-1900. Wraps a WanTI2V; hooks every `WanCrossAttention.forward` of its DiT."""
+
+    def __init__(self, original_wan_pipeline, context_projector, logger, config: CrossAttentionConfig):
+        self.original_pipeline = original_wan_pipeline
+        self.context_projector = context_projector
+        self.logger = logger
+        self.config = config
+        self.dit_model = original_wan_pipeline.model
+        self.original_forward_methods = {}
+        self.fusion_alpha = 1.0
+        self.injection_layers = None
+        self.bagel_context = None
+        self.use_bagel_context = False
+        self.current_timestep = None
+        self.text_weight_multiplier = 1.0
+        self._hook_cross_attention_layers()
+
+    def _calculate_text_weight(self, timestep: int) -> float:
+        """:1699-1735."""
+        c = self.config
+        if not c.use_dynamic_text_weight:
+            return 1.0
+        transition_steps = int(c.total_sampling_steps * c.text_weight_transition_ratio)
+        if timestep >= transition_steps:
+            return c.text_weight_min
+        progress = timestep / max(transition_steps, 1)
+        if c.text_weight_schedule == "linear":
+            return c.text_weight_max - (c.text_weight_max - c.text_weight_min) * progress
+        if c.text_weight_schedule == "cosine":
+            return c.text_weight_min + (c.text_weight_max - c.text_weight_min) * (1 + math.cos(math.pi * progress)) / 2
+        if c.text_weight_schedule == "exponential":
+            return c.text_weight_min + (c.text_weight_max - c.text_weight_min) * math.exp(-5 * progress)
+        return 1.0
+
+    def set_timestep(self, timestep: int):
+        self.current_timestep = timestep
+        self.text_weight_multiplier = self._calculate_text_weight(timestep)
+
+    def _hook_cross_attention_layers(self):
+        """:1742-1810: re-assign `forward` on every WanCrossAttention instance."""
+        layer_idx = 0
+        for name, module in self.dit_model.named_modules():
+            if module.__class__.__name__ != "WanCrossAttention":
+                continue
+            original_forward = module.forward
+            self.original_forward_methods[name] = original_forward
+
+            def make(layer_index, original_fn):
+                def hooked_forward(x, context, context_lens, *args, **kwargs):
+                    if (self.use_bagel_context and self.bagel_context is not None
+                            and (self.injection_layers is None or layer_index in self.injection_layers)
+                            and self.config.use_dynamic_text_weight and self.text_weight_multiplier != 1.0
+                            and context is not None):
+                        seq_len = context.shape[1] if context.dim() > 1 else context.shape[0]
+                        text_len = min(self.config.bagel_sequence_length, seq_len // 2)
+                        weight_mask = torch.ones_like(context)
+                        if context.dim() == 3:
+                            weight_mask[:, :text_len, :] *= self.text_weight_multiplier
+                        elif context.dim() == 2:
+                            weight_mask[:text_len, :] *= self.text_weight_multiplier
+                        context = context * weight_mask
+                    return original_fn(x, context, context_lens, *args, **kwargs)
+                return hooked_forward
+
+            module.forward = make(layer_idx, original_forward)
+            layer_idx += 1
+        self.logger.info(f"Hooked {layer_idx} cross-attention layers")
+
+    def set_bagel_context(self, bagel_tokens, fusion_alpha=None, injection_layers=None):
+        self.bagel_context = self.context_projector(bagel_tokens) if self.context_projector is not None else bagel_tokens
+        self.use_bagel_context = True
+        if fusion_alpha is not None:
+            self.fusion_alpha = fusion_alpha
+        if injection_layers is not None:
+            self.injection_layers = injection_layers
+
+    def clear_bagel_context(self):
+        self.bagel_context = None
+        self.use_bagel_context = False
+
+    def restore_original_methods(self):
+        for name, module in self.dit_model.named_modules():
+            if name in self.original_forward_methods:
+                module.__dict__.pop("forward", None)
+        self.original_forward_methods = {}
+
+    def generate(self, **kwargs):
+        """:1844-1886: wraps the DiT forward with the forward-call counter that drives the text weight."""
+        if not self.config.use_dynamic_text_weight:
+            return self.original_pipeline.generate(**kwargs)
+        self.sampling_step_counter = 0
+        original_dit_forward = self.dit_model.forward
+        wrapper_self = self
+
+        def hooked_dit_forward(hidden_states, t, *args, **kw):
+            wrapper_self.set_timestep(wrapper_self.sampling_step_counter)
+            wrapper_self.sampling_step_counter += 1
+            return original_dit_forward(hidden_states, t, *args, **kw)
+
+        self.dit_model.forward = hooked_dit_forward
+        try:
+            return self.original_pipeline.generate(**kwargs)
+        finally:
+            self.dit_model.__dict__.pop("forward", None)
+            del self.sampling_step_counter
+
+
+class CrossAttentionFusionPipeline:
+    """model_pipeline.py:2110-3230, inference side. Components are injected:
+
+        wan_pipeline     a univid_amd WanTI2V (DiT + VAE + text encoder hook-up)          - the hot path
+        bagel_extractor  object with extract_semantic_tokens(text, image) -> [1, L, 3584]  - off the hot path (stub OK)
+        context_projector callable tokens -> list[[512, 4096]]                             - off the hot path (stub OK)
+    """
+
+    def __init__(self, config: CrossAttentionConfig, wan_pipeline: Optional[WanTI2V] = None, bagel_extractor=None,
+                 context_projector: Optional[Callable] = None, save_fn: Optional[Callable] = None):
+        self.config = config
+        self.logger = logging.getLogger("univid_amd.pipeline")
+        if wan_pipeline is None:
+            raise ValueError("pass wan_pipeline=WanTI2V(...): checkpoints cannot be discovered offline")
+        self.wan_pipeline = wan_pipeline
+        self.bagel_extractor = bagel_extractor
+        self.context_projector = context_projector
+        self.lora_manager = None
+        self.dit_model = wan_pipeline.model
+        self.vae_model = wan_pipeline.vae
+        self.wan_wrapper = Wan22ContextWrapper(wan_pipeline, context_projector, self.logger, config)
+        self.save_fn = save_fn
+
+    def generate_video_with_bagel_context(self, text: str, image=None, **kwargs):
+        """:2577-2655. Returns (video [3, T, H, W] in [-1, 1], path | None). Extra keyword `prompt_embeds` /
+        `negative_prompt_embeds` bypass the (pluggable) text encoder. Unlike the reference, errors propagate."""
+        start = time.time()
+        try:
+            if self.bagel_extractor is not None:
+                tokens = self.bagel_extractor.extract_semantic_tokens(text, image)
+                self.wan_wrapper.set_bagel_context(tokens.to(self.wan_pipeline.device), fusion_alpha=self.config.guidance_strength)
+            params = dict(input_prompt=text, img=image, size=kwargs.get("size", (1280, 704)),
+                          frame_num=kwargs.get("frames", self.config.video_length), shift=kwargs.get("shift", 5.0),
+                          sample_solver="unipc", sampling_steps=kwargs.get("steps", self.config.total_sampling_steps),
+                          guide_scale=kwargs.get("guidance_scale", 5.0), seed=kwargs.get("seed", -1), offload_model=False)
+            for k in ("prompt_embeds", "negative_prompt_embeds", "noise", "decode"):
+                if k in kwargs:
+                    params[k] = kwargs[k]
+            video = self.wan_wrapper.generate(**params)
+            self.logger.info(f"generation time: {time.time() - start:.2f}s")
+            path = self.save_fn(video, text) if (self.save_fn is not None and video is not None) else None
+            return video, path
+        finally:
+            self.wan_wrapper.clear_bagel_context()
+
+    def get_fusion_info(self):
+        return dict(fusion_mode=self.config.fusion_mode, dynamic_text_weight=self.config.use_dynamic_text_weight,
+                    hooked_layers=len(self.wan_wrapper.original_forward_methods))
+
+    def cleanup_resources(self):
+        self.wan_wrapper.restore_original_methods()
