@@ -53,6 +53,27 @@ def build_model(cfg, device, seed=0):
     return m
 
 
+def vae_decode_metric(device):
+    """BASELINE.json's second metric: Wan2.2 VAE decode of a 49-frame 720x1280 clip (config 4), fp32 like the reference
+    (vae2_2.py:897), random-init weights. GB/s = fp32 RGB bytes out / decode time; also the fp32-MFMA fraction
+    (835.4 TFLOP per decode; f32 MFMA peak 157.3 TFLOP/s)."""
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    vae = Wan2_2_VAE(device=device, seed=0)
+    g = torch.Generator(device=device).manual_seed(7)
+    z = torch.randn(48, 13, 45, 80, device=device, generator=g)
+    with torch.no_grad():
+        vae.decode([z[:, :2].contiguous()])                      # warm-up (allocations, kernel load)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        v = vae.decode([z])[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    nbytes = v.numel() * 4
+    return {"metric": "vae_decode_GBps", "value": round(nbytes / dt / 1e9, 4), "unit": "GB/s", "seconds": round(dt, 3),
+            "clip": "49x720x1280 RGB from latent [48,13,45,80]", "dtype": "f32", "tflops": round(835.4 / dt, 1),
+            "mfma_f32_frac": round(835.4 / dt / 157.3, 4), "finite": bool(torch.isfinite(v).all().item())}
+
+
 def cpu_baseline(cfg, budget_s=25.0):
     """Times the CPU restatement (oracle/, validated bit-exact against the reference modules) on this host.
 
@@ -104,6 +125,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer DiT blocks (result is NOT the metric)")
     ap.add_argument("--kernel-times", action="store_true", help="HIP-event timing of every kernel class (adds ~1%% overhead)")
     args = ap.parse_args()
@@ -190,9 +212,14 @@ def main():
             self_ev = [(s, e, f) for s, e, f in prof["uv_flash_attn_bf16"] if f >= self_attn_flops(L_TOKENS, cfg["dim"]) * 0.99]
             avg_ms = sum(s.elapsed_time(e) for s, e, _ in self_ev) / len(self_ev)
             achieved = self_attn_flops(L_TOKENS, cfg["dim"]) / (avg_ms * 1e-3) / 1e12
+            traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.md), not live
+            try:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["self_attention_L11440"]["traffic_bytes_per_launch"]
+            except Exception:
+                pass
             roofline = {"kernel": "flash_attn_fwd_kernel<128> (self-attention, Lq=Lk=11440, 24 heads)", "bound": "mfma",
                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(self_ev),
                         "flops_per_launch": self_attn_flops(L_TOKENS, cfg["dim"])}
         step_flops = 2 * dit_forward_flops(L_TOKENS, cfg)
@@ -211,6 +238,8 @@ def main():
         }
         if args.kernel_times:
             out["kernel_times"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in ktimes.items()}
+        if world == 1 and not args.no_vae and not args.layers:
+            out["vae_decode"] = vae_decode_metric(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dict(TI2V_5B_CFG))
         else:
