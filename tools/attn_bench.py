@@ -1,0 +1,39 @@
+"""Attention-only micro benchmark (developer tool): full-size self-attention launches for profiling."""
+import math, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from univid_amd import _lib
+_lib.init()
+dev = "cuda"; BF16 = torch.bfloat16
+L, H, D = int(os.environ.get("L", 11440)), 24, 128
+C = H * D
+torch.manual_seed(0)
+q = torch.randn(L, C, device=dev).to(BF16); k = torch.randn(L, C, device=dev).to(BF16)
+vt = torch.randn(C, (L + 63) // 64 * 64, device=dev).to(BF16)
+out = torch.empty(L, C, dtype=BF16, device=dev)
+n = int(os.environ.get("N", 5))
+for _ in range(n):
+    _lib.flash_attn(q, k, vt, out, L, L, H, D, 1 / math.sqrt(D))
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(n):
+    _lib.flash_attn(q, k, vt, out, L, L, H, D, 1 / math.sqrt(D))
+e.record(); torch.cuda.synchronize()
+ms = s.elapsed_time(e) / n
+print(f"attention L{L}: {ms:.3f} ms {4*L*L*C/ms/1e9:.1f} TFLOP/s")
+
+if os.environ.get("STAMPS"):
+    import ctypes
+    lib = _lib.load()
+    for nw in (4, 8):
+        nblk = ((L + nw * 32 - 1) // (nw * 32)) * H
+        st = torch.zeros(nblk * nw * 5, dtype=torch.int64, device=dev)
+        fn = lib.uvdbg_flash_attn_stamps
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_long] * 3 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        for _ in range(2):
+            rc = fn(q.data_ptr(), C, k.data_ptr(), C, vt.data_ptr(), vt.stride(0), out.data_ptr(), C, L, L, H, 1 / math.sqrt(D), nw, st.data_ptr(), None)
+        torch.cuda.synchronize()
+        v = st.view(-1, 5).double()
+        tiles = (L + 63) // 64
+        per = v.median(0).values / tiles
+        print(f"nw={nw}: median cycles per tile per wave  qk={per[0]:.0f} softmax={per[1]:.0f} pv={per[2]:.0f} commit={per[3]:.0f} barrier={per[4]:.0f} total={per.sum():.0f}")

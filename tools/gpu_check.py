@@ -264,7 +264,7 @@ def perf():
         w = (torch.randn(N, K, device=dev) * 0.02).to(BF16)
         aa = a if K == C else (torch.randn(L, K, device=dev) * 0.5).to(BF16)
         out = torch.empty(L, N, dtype=BF16, device=dev)
-        for cfg in (1, 2, 3):
+        for cfg in (0, 1, 2, 3, 4):
             ms = timeit(lambda: _lib.gemm_bf16(aa, w, None, out, EPI_BF16, tile_cfg=cfg))
             print(f"  gemm {name} M{L} N{N} K{K} cfg{cfg}: {ms:.3f} ms  {2 * L * N * K / ms / 1e9:.1f} TFLOP/s", flush=True)
     H, D = 24, 128

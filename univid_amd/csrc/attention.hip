@@ -18,13 +18,13 @@
 //   * V arrives already transposed ([H*128, Lk_pad], written by the V-projection GEMM epilogue).
 //   * K tile [64][128] (256-B rows) swizzle chunk ^= row&15; V^T tile [128][64] (128-B rows) swizzle
 //     chunk ^= (row>>1)&7: both make the ds_read_b128 fragment reads bank-conflict-free.
-//   * register-staged double buffer: tile t+1 is fetched to VGPRs before the MFMAs of tile t and
-//     written to the other LDS buffer after them; one barrier per tile.
+//   * LDS-DMA double buffer: tile t+1 is streamed straight into the other LDS buffer (global_load_lds) while tile t
+//     is computed; one vmcnt(0) + one barrier per tile.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 #define UV_ATT_QW 32     // queries per wave
-#define UV_ATT_WAVES 8
-#define UV_ATT_QB (UV_ATT_QW * UV_ATT_WAVES)
 #define UV_ATT_KV 64
 
 struct AttnArgs {
@@ -35,20 +35,26 @@ struct AttnArgs {
     long ldq, ldk, ldvt, ldo;
     int Lq, Lk, H, q_blocks;
     float scale_log2;  // softmax_scale * log2(e)
+    int stagger;       // s_sleep units (64 clk) by which workgroups on odd hardware wave slots start late
 };
+
+typedef __attribute__((address_space(3))) void lds_void_a;
 
 __device__ __forceinline__ int perm23(int i) {  // swap bits 2 and 3
     return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
 
 // D = head_dim (128 for TI2V-5B; 64 for the reference's CPU-runnable tiny config).
-template <int D>
-__global__ __launch_bounds__(UV_ATT_WAVES * 64) void flash_attn_fwd_kernel(AttnArgs p) {
+// NW = waves per workgroup: 8 (256 queries, 1 workgroup per CU) or 4 (128 queries, 2 workgroups per CU: the two waves
+// that share a SIMD then belong to DIFFERENT workgroups, are not re-aligned by a common barrier every tile, and drift
+// into complementary phases - one in its MFMA cluster while the other does softmax VALU work).
+template <int D, int NW, bool STAMP = false>
+__global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, unsigned long long* stamps = nullptr) {
+    constexpr int NT = NW * 64;
     constexpr int KROW = 2 * D;                 // bytes per K row in LDS (256 or 128)
     constexpr int KCH = D / 8;                  // 16-B chunks per K row
     constexpr int NKK = D / 16;                 // MFMA k-steps over the head dim
     constexpr int ND = D / 32;                  // 32-row d tiles of O^T
-    constexpr int NCH = D / 64;                 // staging chunks per thread per operand
     constexpr int K_BYTES = UV_ATT_KV * KROW;   // 16 KiB at D=128
     constexpr int V_BYTES = D * 128;            // 16 KiB at D=128
     constexpr int STAGE = K_BYTES + V_BYTES;
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(UV_ATT_WAVES * 64) void flash_attn_fwd_kernel(AttnA
     // head-major block order: consecutive block ids walk the q-blocks of one head
     const int head = blockIdx.x / p.q_blocks;
     const int qb = blockIdx.x - head * p.q_blocks;
-    const int q0w = qb * UV_ATT_QB + wave * UV_ATT_QW;
+    const int q0w = qb * (NW * UV_ATT_QW) + wave * UV_ATT_QW;
     const long hcol = (long)head * D;
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane (r,h) holds Q[q0w+r][16kk+8h .. +7]
@@ -74,38 +80,46 @@ __global__ __launch_bounds__(UV_ATT_WAVES * 64) void flash_attn_fwd_kernel(AttnA
         for (int kk = 0; kk < NKK; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
     }
 
-    // ---- staging maps: NCH K chunks + NCH V^T chunks (16 B each) per thread per tile
-    const bf16_t* ksrc[NCH];
-    int kdst[NCH], krow[NCH];
-    const bf16_t* vsrc[NCH];
-    int vdst[NCH];
+    // ---- staging: K and V^T tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction,
+    // no VGPR round trip and no ds_write: the VGPR->LDS store path measured 440-700 cycles per tile when all waves of
+    // the CU wrote their 16-byte chunks at once). The LDS image is lane-linear per instruction, so the bank swizzle and
+    // the key-row permutation live in the per-lane SOURCE address:
+    //   K  : one instruction = KPI rows of KROW bytes; LDS row i <- key perm23(i), physical chunk p <- logical chunk
+    //        p ^ key(i)
+    //   V^T: one instruction = 8 rows of 128 B; physical chunk p <- logical chunk p ^ ((row>>1)&7)
+    constexpr int KPI = 1024 / KROW;                  // K rows per wave-instruction (4 at D=128, 8 at D=64)
+    constexpr int K_INSTR = UV_ATT_KV / KPI / NW;     // K wave-instructions per wave per tile
+    constexpr int V_INSTR = D / 8 / NW;               // V^T wave-instructions per wave per tile
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bf16_t* ksrc[K_INSTR];
+    int krow[K_INSTR];
+    const bf16_t* vsrc[V_INSTR];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int id = tid + 512 * i;
-        const int row = id / KCH, c = id % KCH;  // key row in tile, 16-B chunk of the K row
-        const int lrow = perm23(row);
-        krow[i] = row;
+    for (int i = 0; i < K_INSTR; ++i) {
+        const int lrow = (i * NW + wave_u) * KPI + lane / KCH;      // LDS row written by this lane
+        const int pc = lane % KCH;                                  // physical chunk
+        const int c = pc ^ (D == 128 ? (lrow & 15) : ((lrow >> 1) & 7));
+        krow[i] = perm23(lrow);                                     // key row (in tile) stored there
         ksrc[i] = p.k + hcol + c * 8;
-        kdst[i] = lrow * KROW + ((c ^ (D == 128 ? (lrow & 15) : ((lrow >> 1) & 7))) << 4);
-        const int drow = id >> 3, vc = id & 7;  // d row, 16-B chunk (8 keys) of the 128-B row
-        vsrc[i] = p.vt + (hcol + drow) * p.ldvt + vc * 8;
-        vdst[i] = K_BYTES + drow * 128 + ((vc ^ ((drow >> 1) & 7)) << 4);
     }
-    u32x4 kreg[NCH], vreg[NCH];
-    auto fetch = [&](int kv0) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int kr = min(kv0 + krow[i], p.Lk - 1);
-            kreg[i] = *(const u32x4*)(ksrc[i] + (long)kr * p.ldk);
-            vreg[i] = *(const u32x4*)(vsrc[i] + kv0);
-        }
-    };
-    auto commit = [&](int buf) {
+    for (int i = 0; i < V_INSTR; ++i) {
+        const int drow = (i * NW + wave_u) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((drow >> 1) & 7);
+        vsrc[i] = p.vt + (hcol + drow) * p.ldvt + c * 8;
+    }
+    auto fetch = [&](int kv0, int buf) {
         char* base = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            *(u32x4*)(base + kdst[i]) = kreg[i];
-            *(u32x4*)(base + vdst[i]) = vreg[i];
+        for (int i = 0; i < K_INSTR; ++i) {
+            const int kr = min(kv0 + krow[i], p.Lk - 1);
+            const bf16_t* src = ksrc[i] + (long)kr * p.ldk;
+            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(base + (i * NW + wave_u) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < V_INSTR; ++i) {
+            const bf16_t* src = vsrc[i] + kv0;
+            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(base + K_BYTES + (i * NW + wave_u) * 1024), 16, 0, 0);
         }
     };
 
@@ -127,14 +141,53 @@ __global__ __launch_bounds__(UV_ATT_WAVES * 64) void flash_attn_fwd_kernel(AttnA
     float l_run = 0.f;        // this half-wave's partial row sum
 
     const int nt = (p.Lk + UV_ATT_KV - 1) / UV_ATT_KV;
-    fetch(0);
-    commit(0);
+    fetch(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Pin "every prologue load has landed" BEFORE the loop: vmcnt retires in order, so if the compiler has to assume
+    // the Q fragment loads may still be in flight at the loop header it guards their first use inside the loop with
+    // vmcnt(1)/vmcnt(0) - which in steady state waits for the K/V prefetch issued a few instructions earlier and
+    // exposes a full L2/HBM latency in every tile (seen in the ISA; ~1000 cycles of a 4500-cycle tile).
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]));
+    // Phase stagger: the two workgroups (NW = 4) that share a CU run the same program at the same speed, so they stay in
+    // lockstep - both in their MFMA cluster, then both in softmax. Starting the one whose first wave sits on an odd
+    // hardware wave slot half a tile late keeps them in complementary phases for the whole sweep.
+    if (p.stagger > 0) {
+        int* flag = (int*)(smem + 2 * STAGE - 16);   // tail of buffer 1: not yet written (only buffer 0 is filled so far)
+        if (tid == 0) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            *flag = hwid & 1;
+        }
+        __syncthreads();
+        const int late = __builtin_amdgcn_readfirstlane(*flag);
+        if (late) {
+            for (int i = 0; i < p.stagger; i += 8) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
+    // One KV tile. MASKED is a compile-time flag so that the main loop carries no masking code at all (only the ragged
+    // last tile is instantiated with it).
+    // diagnostic build only (STAMP): per-segment cycle sums [qk, softmax, pv, commit, barrier] per wave
+    unsigned long long seg[5] = {0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    auto stamp = [&](int which) {
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (which >= 0) seg[which] += tnow - tprev;
+            tprev = tnow;
+        }
+    };
+    auto tile = [&](int t, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const int kv0 = t * UV_ATT_KV;
+        stamp(-1);
         const char* base = smem + (t & 1) * STAGE;
-        if (t + 1 < nt) fetch(kv0 + UV_ATT_KV);
+        if (t + 1 < nt) fetch(kv0 + UV_ATT_KV, (t + 1) & 1);   // other buffer: last read in tile t-1, fenced by its barrier
 
         // ---- S^T = K . Q^T  (two 32-key tiles)
         f32x16 sacc[2];
@@ -150,8 +203,10 @@ __global__ __launch_bounds__(UV_ATT_WAVES * 64) void flash_attn_fwd_kernel(AttnA
             }
         }
 
+        if (STAMP) { asm volatile("" ::"v"(sacc[0][0]), "v"(sacc[1][15])); }
+        stamp(0);
         // ---- mask the ragged last tile with the TRUE key index of each accumulator row
-        if (kv0 + UV_ATT_KV > p.Lk) {
+        if (MASKED) {
 #pragma unroll
             for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -169,9 +224,18 @@ __global__ __launch_bounds__(UV_ATT_WAVES * 64) void flash_attn_fwd_kernel(AttnA
             for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sacc[T][e]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
         const float mneg = -m_new * p.scale_log2;
-        m_run = m_new;
+        // exact rescale skip: when no row of this wave got a new maximum, alpha == 1 for every lane and the O / l
+        // rescale is the identity (bit-identical result, wave-uniform branch)
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+            m_run = m_new;
+        }
         float psum = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
@@ -184,11 +248,9 @@ __global__ __launch_bounds__(UV_ATT_WAVES * 64) void flash_attn_fwd_kernel(AttnA
                     psum += pv;
                     pf[T][s][j] = (__bf16)pv;
                 }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+        l_run += psum;
+        if (STAMP) { asm volatile("" ::"v"(pf[1][1])); }
+        stamp(1);
 
         // ---- O^T += V^T . P^T
 #pragma unroll
@@ -202,10 +264,22 @@ __global__ __launch_bounds__(UV_ATT_WAVES * 64) void flash_attn_fwd_kernel(AttnA
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[T][s], oacc[d], 0, 0, 0);
                 }
 
-        if (t + 1 < nt) commit((t + 1) & 1);
+        if (STAMP) { asm volatile("" ::"v"(oacc[ND - 1][15])); }
+        stamp(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of tile t+1 has landed in LDS
+        stamp(3);
         __syncthreads();
-    }
+        stamp(4);
+    };
 
+    const int nt_full = p.Lk / UV_ATT_KV;
+    for (int t = 0; t < nt_full; ++t) tile(t, std::false_type{});
+    if (nt_full < nt) tile(nt_full, std::true_type{});
+
+    if (STAMP && stamps && lane == 0) {
+        unsigned long long* dst = stamps + ((long)blockIdx.x * NW + wave) * 5;
+        for (int i = 0; i < 5; ++i) dst[i] = seg[i];
+    }
     // ---- finish: combine the two half-wave sums, normalise, store bf16 rows
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -239,14 +313,45 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
     a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
     a.Lq = Lq; a.Lk = Lk; a.H = H;
-    a.q_blocks = (Lq + UV_ATT_QB - 1) / UV_ATT_QB;
+    // workgroup shape: 4 waves x 2 workgroups per CU by default; UV_ATTN_WAVES=8 selects the 8-wave workgroup (A/B knob)
+    static int nw = 0;
+    if (!nw) {
+        const char* e = getenv("UV_ATTN_WAVES");
+        nw = (e && atoi(e) == 8) ? 8 : 4;
+    }
+    static int stagger = -1;
+    if (stagger < 0) {
+        const char* e = getenv("UV_ATTN_STAGGER");
+        stagger = e ? atoi(e) : 0;
+    }
+    a.stagger = stagger;
+    a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
-    if (head_dim == 128)
-        hipLaunchKernelGGL(flash_attn_fwd_kernel<128>, dim3(a.q_blocks * H), dim3(UV_ATT_WAVES * 64), 0,
-                           (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(flash_attn_fwd_kernel<64>, dim3(a.q_blocks * H), dim3(UV_ATT_WAVES * 64), 0,
-                           (hipStream_t)stream, a);
+    const dim3 grid(a.q_blocks * H), block(nw * 64);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* nostamps = nullptr;
+    if (head_dim == 128 && nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8>), grid, block, 0, st, a, nostamps);
+    else if (head_dim == 128) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4>), grid, block, 0, st, a, nostamps);
+    else if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 8>), grid, block, 0, st, a, nostamps);
+    else hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 4>), grid, block, 0, st, a, nostamps);
     UV_CHECK_LAUNCH("uv_flash_attn_bf16");
+    return 0;
+}
+
+// Developer diagnostic (not part of include/univid_hip.h): the D=128 kernel with per-segment s_memtime stamps.
+// stamps: device buffer of q_blocks*H*nw*5 uint64 cycle sums [qk, softmax, pv, commit, barrier] per wave. Its fences
+// forbid overlaps the real kernel has: read the SHARES, never its run time.
+extern "C" int uvdbg_flash_attn_stamps(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out,
+                                       long ldo, int Lq, int Lk, int H, float softmax_scale, int nw,
+                                       unsigned long long* stamps, void* stream) {
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
+    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.Lq = Lq; a.Lk = Lk; a.H = H; a.stagger = 0;
+    a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
+    a.scale_log2 = softmax_scale * 1.4426950408889634f;
+    const dim3 grid(a.q_blocks * H), block(nw * 64);
+    if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
+    else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
+    UV_CHECK_LAUNCH("uvdbg_flash_attn_stamps");
     return 0;
 }

@@ -306,12 +306,19 @@ extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw,
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
     switch (tile_cfg) {
-        case 0:  // default: pick by size
-            if (M >= 2048 && N >= 1024) return launch_cfg<256, 256, 2, 4>(a, epilogue, s);
-            return launch_cfg<128, 128, 2, 2>(a, epilogue, s);
+        case 0: {  // default: the big tile whose grid quantises best onto the 256 CUs (1 block per CU)
+            if (M < 2048 || N < 1024) return launch_cfg<128, 128, 2, 2>(a, epilogue, s);
+            const long tm = (M + 255) / 256;
+            const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
+            // cost ~ rounds x tile area; 256x192 tiles carry 3/4 of the work of 256x256 at slightly lower efficiency
+            const double c256 = (double)((t256 + 255) / 256) * 1.00, c192 = (double)((t192 + 255) / 256) * 0.78;
+            if (N % 192 == 0 && c192 < c256) return launch_cfg<256, 192, 2, 4>(a, epilogue, s);
+            return launch_cfg<256, 256, 2, 4>(a, epilogue, s);
+        }
         case 1: return launch_cfg<128, 128, 2, 2>(a, epilogue, s);
         case 2: return launch_cfg<256, 256, 2, 4>(a, epilogue, s);
         case 3: return launch_cfg<256, 128, 4, 2>(a, epilogue, s);
+        case 4: return launch_cfg<256, 192, 2, 4>(a, epilogue, s);
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown tile_cfg %d", tile_cfg);
             return -1;
