@@ -232,9 +232,24 @@ def check_vae():
 
 
 def perf_vae():
-    print("== VAE perf (full width)")
     from univid_amd.wan.vae2_2 import Wan2_2_VAE
-    vae = Wan2_2_VAE(device=dev)
+    from oracle import wan_vae
+    g = torch.Generator().manual_seed(3)
+    cfg = wan_vae.SMALL_CFG
+    ora = wan_vae.WanVAE(wan_vae.make_state_dict(cfg, 1), cfg)
+    v3 = Wan2_2_VAE(c_dim=32, dec_dim=32, device=dev, seed=1, precision="bf16x3")
+    for shape in [(48, 3, 2, 3), (48, 2, 4, 2)]:
+        z = torch.randn(*shape, generator=g)
+        with torch.no_grad():
+            ref = ora.decode(z.unsqueeze(0), wan_vae.scale_tensors()).clamp(-1, 1)[0]
+            got = v3.decode([z.to(dev)])[0]
+        stats(f"bf16x3 decode {shape}", got, ref)
+    vid = torch.tanh(torch.randn(3, 9, 32, 48, generator=g))
+    with torch.no_grad():
+        stats("bf16x3 encode", v3.encode([vid.to(dev)])[0], ora.encode(vid.unsqueeze(0), wan_vae.scale_tensors())[0])
+    prec = os.environ.get("VAE_PREC", "bf16x3")
+    print("== VAE perf (full width)", prec)
+    vae = Wan2_2_VAE(device=dev, precision=prec)
     for shape in [(48, 2, 16, 16), (48, 3, 45, 80)]:
         z = torch.randn(*shape, device=dev)
         torch.cuda.synchronize(); t0 = time.time()

@@ -35,7 +35,6 @@ struct AttnArgs {
     long ldq, ldk, ldvt, ldo;
     int Lq, Lk, H, q_blocks;
     float scale_log2;  // softmax_scale * log2(e)
-    int stagger;       // s_sleep units (64 clk) by which workgroups on odd hardware wave slots start late
 };
 
 typedef __attribute__((address_space(3))) void lds_void_a;
@@ -149,22 +148,6 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
     // exposes a full L2/HBM latency in every tile (seen in the ISA; ~1000 cycles of a 4500-cycle tile).
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]));
-    // Phase stagger: the two workgroups (NW = 4) that share a CU run the same program at the same speed, so they stay in
-    // lockstep - both in their MFMA cluster, then both in softmax. Starting the one whose first wave sits on an odd
-    // hardware wave slot half a tile late keeps them in complementary phases for the whole sweep.
-    if (p.stagger > 0) {
-        int* flag = (int*)(smem + 2 * STAGE - 16);   // tail of buffer 1: not yet written (only buffer 0 is filled so far)
-        if (tid == 0) {
-            unsigned hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            *flag = hwid & 1;
-        }
-        __syncthreads();
-        const int late = __builtin_amdgcn_readfirstlane(*flag);
-        if (late) {
-            for (int i = 0; i < p.stagger; i += 8) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     __syncthreads();
 
     // One KV tile. MASKED is a compile-time flag so that the main loop carries no masking code at all (only the ragged
@@ -297,6 +280,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
     }
 }
 
+
 extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
                                   void* out, long ldo, int Lq, int Lk, int H, int head_dim,
                                   float softmax_scale, void* stream) {
@@ -319,12 +303,6 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
         const char* e = getenv("UV_ATTN_WAVES");
         nw = (e && atoi(e) == 8) ? 8 : 4;
     }
-    static int stagger = -1;
-    if (stagger < 0) {
-        const char* e = getenv("UV_ATTN_STAGGER");
-        stagger = e ? atoi(e) : 0;
-    }
-    a.stagger = stagger;
     a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
     const dim3 grid(a.q_blocks * H), block(nw * 64);
@@ -346,7 +324,7 @@ extern "C" int uvdbg_flash_attn_stamps(const void* q, long ldq, const void* k, l
                                        unsigned long long* stamps, void* stream) {
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
-    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.Lq = Lq; a.Lk = Lk; a.H = H; a.stagger = 0;
+    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.Lq = Lq; a.Lk = Lk; a.H = H;
     a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
     const dim3 grid(a.q_blocks * H), block(nw * 64);

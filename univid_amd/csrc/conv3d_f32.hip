@@ -35,7 +35,13 @@ struct ConvArgs {
     int M, tiles_m, tiles_n;
 };
 
-template <int BM, int BN, int WM, int WN>
+// PREC 0: exact-f32 MFMA (v_mfma_f32_16x16x4_f32), weights f32 [Cout][K].
+// PREC 1: "bf16x3": every f32 operand x is split as hi + lo (two bf16), and x*w ~ xh*wh + xh*wl + xl*wh on the bf16 MFMA
+//         (v_mfma_f32_16x16x32_bf16, f32 accumulate). Relative error per product ~1e-5 (the dropped xl*wl term and the
+//         bf16 rounding of lo), i.e. ~100x below the 1e-3 tolerance, at up to 16/3 x the f32-MFMA rate. Weights are
+//         pre-split on the host into [Cout][K/32][32 hi | 32 lo] bf16 (same bytes per row as f32, so the staging code
+//         is shared); activations stay f32 in HBM/LDS and are split in registers.
+template <int BM, int BN, int WM, int WN, int PREC>
 __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -128,21 +134,52 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
         const int buf = kt & 1;
         if (kt + 1 < nk) UV_CONV_STAGE(kt + 1, buf ^ 1);
         const char* base = smem + buf * STAGE;
+        if (PREC == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f32x4 af[TM], wf[TN];
-            const int c = ks * 4 + fq;
+            for (int ks = 0; ks < 2; ++ks) {
+                f32x4 af[TM], wf[TN];
+                const int c = ks * 4 + fq;
 #pragma unroll
-            for (int j = 0; j < TM; ++j) af[j] = *(const f32x4*)(base + a_off[j] + ((c ^ a_key[j]) << 4));
+                for (int j = 0; j < TM; ++j) af[j] = *(const f32x4*)(base + a_off[j] + ((c ^ a_key[j]) << 4));
 #pragma unroll
-            for (int i = 0; i < TN; ++i) wf[i] = *(const f32x4*)(base + w_off[i] + ((c ^ w_key[i]) << 4));
+                for (int i = 0; i < TN; ++i) wf[i] = *(const f32x4*)(base + w_off[i] + ((c ^ w_key[i]) << 4));
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+                    for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], af[j][e], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], af[j][e], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // one K = 32 MFMA step per k-tile: lane (row, fq) owns k = 8*fq .. 8*fq+7 of both operands
+            bf16x8 ah[TM], al[TM], wh[TN], wl[TN];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const f32x4 x0 = *(const f32x4*)(base + a_off[j] + (((2 * fq) ^ a_key[j]) << 4));
+                const f32x4 x1 = *(const f32x4*)(base + a_off[j] + (((2 * fq + 1) ^ a_key[j]) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
+                    ah[j][e] = h0;
+                    ah[j][4 + e] = h1;
+                    al[j][e] = (__bf16)(x0[e] - (float)h0);
+                    al[j][4 + e] = (__bf16)(x1[e] - (float)h1);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                wh[i] = *(const bf16x8*)(base + w_off[i] + ((fq ^ w_key[i]) << 4));
+                wl[i] = *(const bf16x8*)(base + w_off[i] + (((4 + fq) ^ w_key[i]) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ah[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], al[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ah[j], acc[i][j], 0, 0, 0);
+                }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -183,33 +220,85 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
 
 const float* uv_zero_page();
 
-extern "C" int uv_conv3d_f32(const float* in, long ld_in, int Tin, int Hin, int Win, const float* w, const float* bias,
-                             float* out, long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh,
-                             int kw, int st, int sh, int sw, int t_off, int ph, int pw, int up, int interleave,
-                             const float* resid, long ldr, void* stream) {
-    UV_CHECK_ARG(in && w && out, "uv_conv3d_f32: null pointer");
-    UV_CHECK_ARG(Cin % 32 == 0, "uv_conv3d_f32: Cin=%d must be a multiple of 32 (pad channels with zeros)", Cin);
-    UV_CHECK_ARG(Cout % 4 == 0, "uv_conv3d_f32: Cout=%d must be a multiple of 4", Cout);
-    UV_CHECK_ARG(ld_in % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0 && ld_in >= Cin, "uv_conv3d_f32: bad leading dimensions");
-    UV_CHECK_ARG(Tout > 0 && Hout > 0 && Wout > 0 && kt > 0 && kh > 0 && kw > 0, "uv_conv3d_f32: bad geometry");
-    UV_CHECK_ARG(!interleave || (Cout % 8 == 0 && !resid), "uv_conv3d_f32: interleave needs Cout %% 8 == 0 and no residual");
+template <int BM, int BN, int WM, int WN, int PREC>
+static void launch_conv(ConvArgs& a, hipStream_t stream) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    auto kern = conv3d_f32_kernel<BM, BN, WM, WN, PREC>;
+    const size_t lds = 2 * (BM + BN) * 128;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, stream, a);
+}
+
+static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w, const float* bias, float* out,
+                       long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st, int sh,
+                       int sw, int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr, int prec,
+                       void* stream) {
+    UV_CHECK_ARG(in && w && out, "uv_conv3d: null pointer");
+    UV_CHECK_ARG(Cin % 32 == 0, "uv_conv3d: Cin=%d must be a multiple of 32 (pad channels with zeros)", Cin);
+    UV_CHECK_ARG(Cout % 4 == 0, "uv_conv3d: Cout=%d must be a multiple of 4", Cout);
+    UV_CHECK_ARG(ld_in % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0 && ld_in >= Cin, "uv_conv3d: bad leading dimensions");
+    UV_CHECK_ARG(Tout > 0 && Hout > 0 && Wout > 0 && kt > 0 && kh > 0 && kw > 0, "uv_conv3d: bad geometry");
+    UV_CHECK_ARG(!interleave || (Cout % 8 == 0 && !resid), "uv_conv3d: interleave needs Cout %% 8 == 0 and no residual");
     UV_CHECK_ARG((((uintptr_t)in | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)resid) & 15) == 0,
-                 "uv_conv3d_f32: pointers must be 16-byte aligned");
+                 "uv_conv3d: pointers must be 16-byte aligned");
     ConvArgs a;
-    a.in = in; a.w = w; a.bias = bias; a.resid = resid; a.out = out; a.zeros = uv_zero_page();
-    UV_CHECK_ARG(a.zeros, "uv_conv3d_f32: zero page missing (call uv_init)");
+    a.in = in; a.w = (const float*)w; a.bias = bias; a.resid = resid; a.out = out; a.zeros = uv_zero_page();
+    UV_CHECK_ARG(a.zeros, "uv_conv3d: zero page missing (call uv_init)");
     a.ld_in = ld_in; a.ldo = ldo; a.ldr = ldr;
     a.Tout = Tout; a.Hout = Hout; a.Wout = Wout; a.Tin = Tin; a.Hin = Hin; a.Win = Win;
     a.Cin = Cin; a.Cout = Cout; a.kt = kt; a.kh = kh; a.kw = kw; a.st = st; a.sh = sh; a.sw = sw;
     a.t_off = t_off; a.ph = ph; a.pw = pw; a.up = up; a.interleave = interleave;
     a.M = Tout * Hout * Wout;
-    constexpr int BM = 128, BN = 128;
-    a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (Cout + BN - 1) / BN;
-    auto kern = conv3d_f32_kernel<BM, BN, 2, 2>;
-    const size_t lds = 2 * (BM + BN) * 128;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, (hipStream_t)stream, a);
-    UV_CHECK_LAUNCH("uv_conv3d_f32");
+    hipStream_t s = (hipStream_t)stream;
+    if (prec == 0) {
+        launch_conv<128, 128, 2, 2, 0>(a, s);
+    } else {
+        // big tile (8 waves) once it fills the chip, else the 4-wave tile for the low-resolution stages
+        const long big = (long)((a.M + 255) / 256) * ((Cout + 127) / 128);
+        if (big >= 256) launch_conv<256, 128, 4, 2, 1>(a, s);
+        else launch_conv<128, 128, 2, 2, 1>(a, s);
+    }
+    UV_CHECK_LAUNCH("uv_conv3d");
+    return 0;
+}
+
+extern "C" int uv_conv3d_f32(const float* in, long ld_in, int Tin, int Hin, int Win, const float* w, const float* bias,
+                             float* out, long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh,
+                             int kw, int st, int sh, int sw, int t_off, int ph, int pw, int up, int interleave,
+                             const float* resid, long ldr, void* stream) {
+    return conv_common(in, ld_in, Tin, Hin, Win, w, bias, out, ldo, Tout, Hout, Wout, Cin, Cout, kt, kh, kw, st, sh, sw, t_off,
+                       ph, pw, up, interleave, resid, ldr, 0, stream);
+}
+
+// Same convolution with split-bf16 (3-pass) arithmetic. w_split: [Cout][K/32][32 hi | 32 lo] bf16 (uv_split_weights_bf16x3).
+extern "C" int uv_conv3d_bf16x3(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w_split,
+                                const float* bias, float* out, long ldo, int Tout, int Hout, int Wout, int Cin, int Cout,
+                                int kt, int kh, int kw, int st, int sh, int sw, int t_off, int ph, int pw, int up,
+                                int interleave, const float* resid, long ldr, void* stream) {
+    return conv_common(in, ld_in, Tin, Hin, Win, w_split, bias, out, ldo, Tout, Hout, Wout, Cin, Cout, kt, kh, kw, st, sh, sw,
+                       t_off, ph, pw, up, interleave, resid, ldr, 1, stream);
+}
+
+// w [rows][K] f32 (K % 32 == 0) -> [rows][K/32][32 hi | 32 lo] bf16, hi = bf16(w), lo = bf16(w - hi)
+__global__ void split_weights_kernel(const float* w, bf16_t* out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float x = w[i];
+        const bf16_t h = f2bf(x);
+        const long blk = i >> 5, e = i & 31;
+        out[blk * 64 + e] = h;
+        out[blk * 64 + 32 + e] = f2bf(x - bf2f(h));
+    }
+}
+
+extern "C" int uv_split_weights_bf16x3(const float* w, void* out, long n, void* stream) {
+    UV_CHECK_ARG(w && out && n > 0 && n % 32 == 0, "uv_split_weights_bf16x3: n must be a positive multiple of 32");
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)min((n + 255) / 256, (long)4096)), dim3(256), 0, (hipStream_t)stream, w,
+                       (bf16_t*)out, n);
+    UV_CHECK_LAUNCH("uv_split_weights_bf16x3");
     return 0;
 }

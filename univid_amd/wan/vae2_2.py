@@ -167,7 +167,15 @@ class _ConvOp:
         self.w = wp.reshape(self.cout, -1).contiguous()
         self.w2d = w.reshape(self.cout, self.cin).contiguous() if (self.kt, self.kh, self.kw) == (1, 1, 1) else None
         self.b = conv.bias.detach().float().contiguous()
+        self.w_split = None
         self.rings = {}
+
+    def split(self):
+        """bf16 hi/lo planes of the weights for the bf16x3 kernel ([Cout][K/32][32 hi | 32 lo])."""
+        if self.w_split is None:
+            self.w_split = torch.empty(self.w.numel() * 2, dtype=torch.bfloat16, device=self.w.device)
+            _lib.call("uv_split_weights_bf16x3", _lib.ptr(self.w), _lib.ptr(self.w_split), self.w.numel(), _lib.stream_ptr())
+        return self.w_split
 
     def ring(self, H, W, tmax, prefix=CACHE_T):
         key = (H, W, tmax, prefix)
@@ -185,8 +193,11 @@ def _shift(ring, T, prefix=CACHE_T):
 
 
 class _Engine:
-    def __init__(self, model: "WanVAE_"):
+    def __init__(self, model: "WanVAE_", precision="fp32"):
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError("precision must be 'fp32' (exact, like the reference) or 'bf16x3' (split-bf16 MFMA, ~1e-5)")
         self.m = model
+        self.precision = precision
         self.ops = {}
         for name, mod in model.named_modules():
             if isinstance(mod, nn.Conv3d):
@@ -209,7 +220,9 @@ class _Engine:
         if out is None:
             out = torch.empty(tt, Hout, Wout, cout, dtype=torch.float32, device=self.dev)
             ldo = cout
-        _lib.call("uv_conv3d_f32", _lib.ptr(src), src.stride(-2), Tin, Hin, Win, _lib.ptr(op.w), _lib.ptr(op.b), _lib.ptr(out),
+        fast = self.precision == "bf16x3"
+        _lib.call("uv_conv3d_bf16x3" if fast else "uv_conv3d_f32", _lib.ptr(src), src.stride(-2), Tin, Hin, Win,
+                  _lib.ptr(op.split() if fast else op.w), _lib.ptr(op.b), _lib.ptr(out),
                   ldo, Tout, Hout, Wout, op.cin_pad, op.cout, op.kt, op.kh, op.kw, st, sh, sw, t_off, ph, pw, up, interleave,
                   _lib.ptr(resid), 0 if resid is None else resid.stride(-2), _lib.stream_ptr(),
                   flops=2 * Tout * Hout * Wout * op.cout * op.kt * op.kh * op.kw * op.cin)
@@ -367,16 +380,21 @@ class WanVAE_(nn.Module):
         self.conv2 = CausalConv3d(z_dim, z_dim, 1)
         self.decoder = Decoder3d(dec_dim, z_dim, dim_mult, num_res_blocks, attn_scales, self.temperal_upsample, dropout)
         self._engine = None
+        self.precision = "fp32"
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
 
     def invalidate(self):
         self._engine = None
 
-    def prepare(self):
+    def prepare(self, precision=None):
+        """precision: 'fp32' = exact f32 MFMA (the reference's dtype, default) | 'bf16x3' = split-bf16 3-pass MFMA for the
+        3x3(x3) convolutions (everything else stays fp32), ~1e-5 relative error, several times faster."""
         if next(self.parameters()).device.type != "cuda":
             raise _lib.UnividHipError("WanVAE_.prepare: parameters must be on the GPU - there is no CPU path in univid_amd")
         _lib.init()
-        self._engine = _Engine(self)
+        if precision is not None:
+            self.precision = precision
+        self._engine = _Engine(self, self.precision)
         return self
 
     def _eng(self):
@@ -441,7 +459,7 @@ class Wan2_2_VAE:
     a path loads the reference checkpoint (same state-dict keys)."""
 
     def __init__(self, z_dim=48, c_dim=160, vae_pth=None, dim_mult=(1, 2, 4, 4), temperal_downsample=(False, True, True),
-                 dtype=torch.float, device="cuda", dec_dim=256, seed=0):
+                 dtype=torch.float, device="cuda", dec_dim=256, seed=0, precision="fp32"):
         self.dtype = dtype
         self.device = torch.device(device)
         mean = torch.tensor(_MEAN, dtype=dtype, device=device)
@@ -456,6 +474,7 @@ class Wan2_2_VAE:
         else:
             model.init_weights(seed)
         self.model = model.eval().requires_grad_(False).to(device)
+        self.model.precision = precision
 
     def encode(self, videos):
         if not isinstance(videos, list):
