@@ -338,6 +338,43 @@ def test_dit_block_ti2v5b_width_vs_golden():
     assert torch.equal(x, out[0]), "row-table modulation must equal the per-token modulation bit for bit"
 
 
+def test_dit_block_ti2v5b_width_1014_tokens_vs_oracle():
+    """BASELINE config 2 ("HIP DiT block vs reference eager, numerics gate") at a bounded size: one TI2V-5B-width block,
+    L = 13 x 6 x 13 = 1014 tokens (16 KV tiles, ragged last tile, 8 query blocks), two distinct timesteps, against the CPU
+    oracle run here (too large for a committed fixture)."""
+    from oracle import wan_dit
+    from univid_amd import detinit
+    from univid_amd.wan.model import WanAttentionBlock, _freqs_device, rope_params
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    dim, ffn, heads, grid = 3072, 14336, 24, (13, 6, 13)
+    Lt = grid[0] * grid[1] * grid[2]
+    with torch.device(DEV):
+        blk = WanAttentionBlock(dim, ffn, heads, (-1, -1), True, True, 1e-6)
+    sd = {"blocks.0." + k: v for k, v in blk.state_dict(keep_vars=True).items()}
+    detinit.init_state_dict_(sd, 11)
+    blk.eval()
+    sdc = {k: v.detach().cpu() for k, v in sd.items()}
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, Lt, dim, generator=g)
+    e_rows = torch.randn(2, 6, dim, generator=g) * 0.3
+    tid = (torch.arange(Lt) >= grid[1] * grid[2]).long()              # first latent frame at its own timestep (i2v)
+    ctx = (torch.randn(1, 512, dim, generator=g) * 0.5).to(BF16)
+    d = dim // heads
+    freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)), rope_params(1024, 2 * (d // 6))], dim=1)
+    e0 = e_rows[tid].unsqueeze(0)
+    with torch.no_grad():
+        ref = wan_dit.block_forward(sdc, "blocks.0.", x, e0, torch.tensor([Lt]), torch.tensor([grid]), freqs, ctx, heads, 1e-6)
+        old, wan_dit.BF16 = wan_dit.BF16, torch.float32
+        try:
+            truth = wan_dit.block_forward(sdc, "blocks.0.", x, e0, torch.tensor([Lt]), torch.tensor([grid]), freqs, ctx.float(), heads, 1e-6)
+        finally:
+            wan_dit.BF16 = old
+        xs = x[0].to(DEV).clone()
+        blk._run(xs, Lt, e_rows.reshape(2, -1).to(DEV), tid.to(torch.int32).to(DEV), grid, _freqs_device(freqs, torch.device(DEV)),
+                 ctx[0].to(DEV), first_block=False)
+    assert_model_close(xs, ref[0], truth[0], frac=0.70, name="TI2V-5B block, L=1014")
+
+
 def test_sampler_trajectories_vs_golden():
     from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
     g = load_golden("sampler_tiny")
