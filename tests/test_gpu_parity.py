@@ -370,6 +370,7 @@ def test_dit_block_ti2v5b_width_1014_tokens_vs_oracle():
         finally:
             wan_dit.BF16 = old
         xs = x[0].to(DEV).clone()
+        blk.prepare()
         blk._run(xs, Lt, e_rows.reshape(2, -1).to(DEV), tid.to(torch.int32).to(DEV), grid, _freqs_device(freqs, torch.device(DEV)),
                  ctx[0].to(DEV), first_block=False)
     assert_model_close(xs, ref[0], truth[0], frac=0.70, name="TI2V-5B block, L=1014")
