@@ -167,8 +167,8 @@ def main():
     def one_step(i, lat):
         t = timesteps[i]
         tvec = torch.full((1, seq_len), float(t), device=device)
-        cond = model([lat], t=tvec, context=ctx, seq_len=seq_len)[0]
-        uncond = model([lat], t=tvec, context=ctx_null, seq_len=seq_len)[0]
+        # exactly what WanTI2V.denoise does per timestep: the CFG pair as one stacked pass (bit-identical per sample)
+        cond, uncond = model([lat, lat], t=torch.cat([tvec, tvec]), context=[ctx[0], ctx_null[0]], seq_len=seq_len)
         return sched.step_cfg(cond.unsqueeze(0), uncond.unsqueeze(0), GUIDE, t, lat.unsqueeze(0)).squeeze(0)
 
     def barrier():
@@ -213,17 +213,19 @@ def main():
             # self-attention launches only (Lk == L); cross-attention launches (Lk = 512) are tagged with fewer flops
             self_ev = [(s, e, f) for s, e, f in prof["uv_flash_attn_bf16"] if f >= self_attn_flops(L_TOKENS, cfg["dim"]) * 0.99]
             avg_ms = sum(s.elapsed_time(e) for s, e, _ in self_ev) / len(self_ev)
-            achieved = self_attn_flops(L_TOKENS, cfg["dim"]) / (avg_ms * 1e-3) / 1e12
+            launch_flops = self_ev[0][2]     # 2 samples (cond + uncond) per launch
+            achieved = launch_flops / (avg_ms * 1e-3) / 1e12
             traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.md), not live
             try:
                 traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["self_attention_L11440"]["traffic_bytes_per_launch"]
+                traffic *= prof["uv_flash_attn_bf16"][0][2] / self_attn_flops(L_TOKENS, cfg["dim"])   # samples per launch
             except Exception:
                 pass
-            roofline = {"kernel": "flash_attn_fwd_kernel<128> (self-attention, Lq=Lk=11440, 24 heads)", "bound": "mfma",
+            roofline = {"kernel": "flash_attn_fwd_kernel<128> (self-attention, cond+uncond batch 2 x Lq=Lk=11440, 24 heads)", "bound": "mfma",
                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(self_ev),
-                        "flops_per_launch": self_attn_flops(L_TOKENS, cfg["dim"])}
+                        "flops_per_launch": launch_flops}
         step_flops = 2 * dit_forward_flops(L_TOKENS, cfg)
         out = {
             "metric": "denoise_steps_per_sec", "value": round(world * args.steps / dt_max, 4), "unit": "steps/s",

@@ -51,12 +51,13 @@ int uv_gemm_f32_nt(const float* A, long lda, const float* W, long ldw, const flo
                    long ldo, const float* resid, long ldr, void* stream);
 
 /* ---- DiT: attention ---------------------------------------------------------------------------------------- */
-/* out[Lq, H*D] = softmax(q k^T * softmax_scale) v per head, non-causal, all Lk keys attended.
- * Replaces flash_attention() (attention.py:24-130) as called at model.py:145-150 and :175.
- * q [Lq, ldq], k [Lk, ldk] bf16 with head h at columns [h*D, (h+1)*D); vt = V TRANSPOSED, bf16 [H*D, ldvt] with
- * ldvt >= roundup(Lk, 64) and finite padding; head_dim D in {64, 128}. */
+/* out[Lq, H*D] = softmax(q k^T * softmax_scale) v per head, non-causal, all Lk keys attended, for `batch` independent
+ * samples. Replaces flash_attention() (attention.py:24-130) as called at model.py:145-150 and :175.
+ * q [batch*Lq, ldq], k [batch*Lk, ldk] bf16 (samples stacked along the token axis) with head h at columns
+ * [h*D, (h+1)*D); vt = V TRANSPOSED, bf16 [batch*H*D, ldvt] (samples stacked along the channel-row axis) with
+ * ldvt >= roundup(Lk, 64) and finite padding; out [batch*Lq, ldo]; head_dim D in {64, 128}. */
 int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
-                       int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream);
+                       int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream);
 
 /* ---- DiT: fused HBM-bound glue ------------------------------------------------------------------------------ */
 /* LayerNorm(no affine) over C then mode 0: y | 1: y*(1+scale[t])+shift[t] (t = tid[row]) | 2: y*w+b.

@@ -283,6 +283,29 @@ def test_dit_tiny_forward_vs_golden():
     assert torch.equal(t1d, one), "t of shape [B] must equal the expanded [B, seq_len] form"
 
 
+def test_dit_batched_forward_is_bit_identical_to_sequential():
+    """Samples of equal shape run as one stacked pass (the CFG cond/uncond pair in WanTI2V.denoise): per-sample results
+    must not change by a single bit; mixed shapes fall back to one-by-one."""
+    g = load_golden("dit_tiny")
+    cfg, sd, m = _tiny_model(g["seed"])
+    Lt = 256
+    gen = torch.Generator().manual_seed(5)
+    x2 = torch.randn(48, 4, 16, 16, generator=gen)
+    ctx2 = torch.randn(7, cfg["text_dim"], generator=gen)
+    xa, xb = g["x"].to(DEV), x2.to(DEV)
+    ca, cb = g["ctx"].to(DEV), ctx2.to(DEV)
+    ta, tb = g["t_two"].to(DEV), torch.full((1, Lt), 321.0, device=DEV)
+    with torch.no_grad():
+        a = m([xa], ta, [ca], Lt)[0]
+        b = m([xb], tb, [cb], Lt)[0]
+        both = m([xa, xb], torch.cat([ta, tb]), [ca, cb], Lt)
+        small = torch.randn(48, 2, 8, 8, generator=gen).to(DEV)
+        mixed = m([xa, small], torch.cat([ta, tb]), [ca, cb], Lt)
+        s_alone = m([small], tb, [cb], Lt)[0]
+    assert torch.equal(both[0], a) and torch.equal(both[1], b)
+    assert torch.equal(mixed[0], a) and torch.equal(mixed[1], s_alone)
+
+
 def test_dit_head_dim_128_and_odd_grid():
     from oracle import wan_dit
     cfg, sd, m = _tiny_model(3, num_heads=2)

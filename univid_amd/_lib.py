@@ -23,7 +23,7 @@ SIGNATURES = {
     "uv_device_arch": [_c.c_char_p, _I],
     "uv_gemm_bf16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
     "uv_gemm_f32_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _P],
-    "uv_flash_attn_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P],
+    "uv_flash_attn_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "uv_layernorm_mod": [_P, _L, _P, _L, _I, _I, _F, _I, _P, _L, _I, _I, _P, _P, _P, _I, _I, _P],
     "uv_rmsnorm_rope": [_P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _I, _I, _I, _P],
     "uv_patchify_bf16": [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -163,11 +163,12 @@ def gemm_f32(a, w, bias, out, resid=None, M=None):
     return out
 
 
-def flash_attn(q, k, vt, out, Lq, Lk, H, D, scale):
+def flash_attn(q, k, vt, out, Lq, Lk, H, D, scale, batch=1):
+    """q [batch*Lq, C], k [batch*Lk, C], vt [batch*C, >= roundup(Lk, 64)], out [batch*Lq, C]; C = H*D."""
     for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (out, "out")):
         _chk(t, torch.bfloat16, "flash_attn." + n)
     call("uv_flash_attn_bf16", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(vt), vt.stride(0), ptr(out), out.stride(0),
-         Lq, Lk, H, D, float(scale), stream_ptr(), flops=4 * Lq * Lk * H * D)
+         batch, Lq, Lk, H, D, float(scale), stream_ptr(), flops=4 * batch * Lq * Lk * H * D)
     return out
 
 

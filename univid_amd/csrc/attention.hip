@@ -33,7 +33,7 @@ struct AttnArgs {
     const bf16_t* vt;  // [H*128, ldvt]  (V transposed; ldvt >= roundup(Lk, 64), pad finite)
     bf16_t* out;       // [Lq, ldo]
     long ldq, ldk, ldvt, ldo;
-    int Lq, Lk, H, q_blocks;
+    int Lq, Lk, H, q_blocks, batch;
     float scale_log2;  // softmax_scale * log2(e)
 };
 
@@ -64,9 +64,17 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
     const int wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    // head-major block order: consecutive block ids walk the q-blocks of one head
-    const int head = blockIdx.x / p.q_blocks;
-    const int qb = blockIdx.x - head * p.q_blocks;
+    // (sample, head)-major block order: consecutive block ids walk the q-blocks of one head of one sample
+    const int bh = blockIdx.x / p.q_blocks;
+    const int qb = blockIdx.x - bh * p.q_blocks;
+    const int head = bh % p.H;
+    {   // independent samples are stacked along the token axis (q/k/out) resp. along the channel-row axis (V^T)
+        const long b = bh / p.H;
+        p.q += b * p.Lq * p.ldq;
+        p.k += b * p.Lk * p.ldk;
+        p.vt += b * p.H * D * p.ldvt;
+        p.out += b * p.Lq * p.ldo;
+    }
     const int q0w = qb * (NW * UV_ATT_QW) + wave * UV_ATT_QW;
     const long hcol = (long)head * D;
 
@@ -282,11 +290,11 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
 
 
 extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
-                                  void* out, long ldo, int Lq, int Lk, int H, int head_dim,
+                                  void* out, long ldo, int batch, int Lq, int Lk, int H, int head_dim,
                                   float softmax_scale, void* stream) {
     UV_CHECK_ARG(q && k && vt && out, "uv_flash_attn_bf16: null pointer");
     UV_CHECK_ARG(head_dim == 128 || head_dim == 64, "uv_flash_attn_bf16: head_dim %d unsupported (64 or 128)", head_dim);
-    UV_CHECK_ARG(Lq > 0 && Lk > 0 && H > 0, "uv_flash_attn_bf16: bad shape Lq=%d Lk=%d H=%d", Lq, Lk, H);
+    UV_CHECK_ARG(Lq > 0 && Lk > 0 && H > 0 && batch > 0, "uv_flash_attn_bf16: bad shape B=%d Lq=%d Lk=%d H=%d", batch, Lq, Lk, H);
     UV_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0,
                  "uv_flash_attn_bf16: leading dimensions must be multiples of 8 elements");
     UV_CHECK_ARG(ldvt >= (long)((Lk + 63) / 64) * 64,
@@ -296,7 +304,7 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
     a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
-    a.Lq = Lq; a.Lk = Lk; a.H = H;
+    a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = batch;
     // workgroup shape: 4 waves x 2 workgroups per CU by default; UV_ATTN_WAVES=8 selects the 8-wave workgroup (A/B knob)
     static int nw = 0;
     if (!nw) {
@@ -305,7 +313,7 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
     }
     a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
-    const dim3 grid(a.q_blocks * H), block(nw * 64);
+    const dim3 grid(a.q_blocks * H * batch), block(nw * 64);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* nostamps = nullptr;
     if (head_dim == 128 && nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8>), grid, block, 0, st, a, nostamps);
@@ -324,7 +332,7 @@ extern "C" int uvdbg_flash_attn_stamps(const void* q, long ldq, const void* k, l
                                        unsigned long long* stamps, void* stream) {
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
-    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.Lq = Lq; a.Lk = Lk; a.H = H;
+    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = 1;
     a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
     const dim3 grid(a.q_blocks * H), block(nw * 64);

@@ -87,22 +87,27 @@ class WanSelfAttention(nn.Module):
     def prepare(self):
         self._prep = {n: _Prepared(getattr(self, n)) for n in ("q", "k", "v", "o")}
 
-    def _self_attn(self, h, L, grid, freqs, x_resid, gate, gate_tid):
-        """h: bf16 [L, C] modulated input. Adds o(attn) * gate into x_resid (fp32) in the GEMM epilogue."""
+    def _self_attn(self, h, L, grid, freqs, x_resid, gate, gate_tid, batch=1):
+        """h: bf16 [batch*L, C] modulated input (samples stacked along the token axis). Adds o(attn) * gate into x_resid
+        (fp32) in the GEMM epilogue."""
         C, H, D = self.dim, self.num_heads, self.head_dim
         p = self._prep
         dev = h.device
-        ql = torch.empty(L, C, dtype=BF16, device=dev)
-        kl = torch.empty(L, C, dtype=BF16, device=dev)
-        vt = _zeros_cached(("vt", C, _round_up(L, 64), dev), (C, _round_up(L, 64)), BF16, dev)
-        _lib.gemm_bf16(h, p["q"].w, p["q"].b, ql, EPI_BF16, M=L)
-        _lib.gemm_bf16(h, p["k"].w, p["k"].b, kl, EPI_BF16, M=L)
-        _lib.gemm_bf16(h, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=L)
-        _lib.rmsnorm_rope(ql, ql, self.norm_q.weight, L, C, D, self.eps, freqs, grid)
-        _lib.rmsnorm_rope(kl, kl, self.norm_k.weight, L, C, D, self.eps, freqs, grid)
-        att = torch.empty(L, C, dtype=BF16, device=dev)
-        _lib.flash_attn(ql, kl, vt, att, L, L, H, D, 1.0 / math.sqrt(D))
-        _lib.gemm_bf16(att, p["o"].w, p["o"].b, x_resid, EPI_GATE_RESID_F32, M=L, gate=gate, gate_tid=gate_tid)
+        M = batch * L
+        ql = torch.empty(M, C, dtype=BF16, device=dev)
+        kl = torch.empty(M, C, dtype=BF16, device=dev)
+        Lp = _round_up(L, 64)
+        vt = _zeros_cached(("vt", batch * C, Lp, dev), (batch * C, Lp), BF16, dev)
+        _lib.gemm_bf16(h, p["q"].w, p["q"].b, ql, EPI_BF16, M=M)
+        _lib.gemm_bf16(h, p["k"].w, p["k"].b, kl, EPI_BF16, M=M)
+        for b in range(batch):   # V^T and RoPE are per sample (transposed output / token position)
+            rows = slice(b * L, (b + 1) * L)
+            _lib.gemm_bf16(h[rows], p["v"].w, p["v"].b, vt[b * C:(b + 1) * C], EPI_BF16_T, M=L)
+            _lib.rmsnorm_rope(ql[rows], ql[rows], self.norm_q.weight, L, C, D, self.eps, freqs, grid)
+            _lib.rmsnorm_rope(kl[rows], kl[rows], self.norm_k.weight, L, C, D, self.eps, freqs, grid)
+        att = torch.empty(M, C, dtype=BF16, device=dev)
+        _lib.flash_attn(ql, kl, vt, att, L, L, H, D, 1.0 / math.sqrt(D), batch=batch)
+        _lib.gemm_bf16(att, p["o"].w, p["o"].b, x_resid, EPI_GATE_RESID_F32, M=M, gate=gate, gate_tid=gate_tid)
 
     def forward(self, x, seq_lens, grid_sizes, freqs):
         """Reference signature (model.py:126-155): x [B, L, C] -> [B, L, C] bf16. Keys >= seq_lens[b] are masked,
@@ -138,27 +143,29 @@ class WanCrossAttention(WanSelfAttention):
     part of UniVid's contract: Wan22ContextWrapper finds modules by `__class__.__name__ == 'WanCrossAttention'`
     and replaces `module.forward` with a closure that rescales `context` (model_pipeline.py:1745-1807)."""
 
-    def _attend(self, hq, ctx, L, Lc):
-        """hq bf16 [L, C] (normed queries' input), ctx bf16 [Lc, C] -> attention output bf16 [L, C] (pre-o)."""
+    def _attend(self, hq, ctx, L, Lc, batch=1):
+        """hq bf16 [batch*L, C] (normed queries' input), ctx bf16 [batch*Lc, C] -> attention output bf16 [batch*L, C]."""
         C, H, D = self.dim, self.num_heads, self.head_dim
         p = self._prep
         dev = hq.device
-        ql = torch.empty(L, C, dtype=BF16, device=dev)
-        kl = torch.empty(Lc, C, dtype=BF16, device=dev)
-        vt = _zeros_cached(("cvt", C, _round_up(Lc, 64), dev), (C, _round_up(Lc, 64)), BF16, dev)
-        _lib.gemm_bf16(hq, p["q"].w, p["q"].b, ql, EPI_BF16, M=L)
-        _lib.gemm_bf16(ctx, p["k"].w, p["k"].b, kl, EPI_BF16, M=Lc)
-        _lib.gemm_bf16(ctx, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=Lc)
-        _lib.rmsnorm_rope(ql, ql, self.norm_q.weight, L, C, D, self.eps)
-        _lib.rmsnorm_rope(kl, kl, self.norm_k.weight, Lc, C, D, self.eps)
-        att = torch.empty(L, C, dtype=BF16, device=dev)
-        _lib.flash_attn(ql, kl, vt, att, L, Lc, H, D, 1.0 / math.sqrt(D))
+        ql = torch.empty(batch * L, C, dtype=BF16, device=dev)
+        kl = torch.empty(batch * Lc, C, dtype=BF16, device=dev)
+        Lcp = _round_up(Lc, 64)
+        vt = _zeros_cached(("cvt", batch * C, Lcp, dev), (batch * C, Lcp), BF16, dev)
+        _lib.gemm_bf16(hq, p["q"].w, p["q"].b, ql, EPI_BF16, M=batch * L)
+        _lib.gemm_bf16(ctx, p["k"].w, p["k"].b, kl, EPI_BF16, M=batch * Lc)
+        for b in range(batch):
+            _lib.gemm_bf16(ctx[b * Lc:(b + 1) * Lc], p["v"].w, p["v"].b, vt[b * C:(b + 1) * C], EPI_BF16_T, M=Lc)
+        _lib.rmsnorm_rope(ql, ql, self.norm_q.weight, batch * L, C, D, self.eps)
+        _lib.rmsnorm_rope(kl, kl, self.norm_k.weight, batch * Lc, C, D, self.eps)
+        att = torch.empty(batch * L, C, dtype=BF16, device=dev)
+        _lib.flash_attn(ql, kl, vt, att, L, Lc, H, D, 1.0 / math.sqrt(D), batch=batch)
         return att
 
-    def _cross_fused(self, hq, ctx, L, Lc, x_resid):
-        att = self._attend(hq, ctx, L, Lc)
+    def _cross_fused(self, hq, ctx, L, Lc, x_resid, batch=1):
+        att = self._attend(hq, ctx, L, Lc, batch)
         p = self._prep["o"]
-        _lib.gemm_bf16(att, p.w, p.b, x_resid, EPI_RESID_F32, M=L)
+        _lib.gemm_bf16(att, p.w, p.b, x_resid, EPI_RESID_F32, M=batch * L)
 
     def forward(self, x, context, context_lens=None):
         """x [B, L1, C], context [B, L2, C] -> [B, L1, C] bf16 (the caller adds it to the residual stream)."""
@@ -195,12 +202,13 @@ class WanAttentionBlock(nn.Module):
         self.cross_attn.prepare()
         self._prep = {"ffn0": _Prepared(self.ffn[0]), "ffn2": _Prepared(self.ffn[2])}
 
-    def _run(self, x, L, e0_rows, tid, grid, freqs, ctx, first_block):
-        """x: fp32 [L, C] residual stream, updated IN PLACE. e0_rows: fp32 [n_t, 6C]; tid int32 [L] | None;
-        ctx: bf16 [Lc, C] embedded context."""
+    def _run(self, x, L, e0_rows, tid, grid, freqs, ctx, first_block, batch=1):
+        """x: fp32 [batch*L, C] residual stream (independent samples stacked along the token axis), updated IN PLACE.
+        e0_rows: fp32 [n_t, 6C]; tid int32 [batch*L] | None; ctx: bf16 [batch*Lc, C] embedded context(s)."""
         C = self.dim
         dev = x.device
         n_t = e0_rows.shape[0]
+        Ls, L = L, batch * L          # Ls = tokens per sample; L = rows of every row-wise kernel below
         tab = torch.empty(n_t, 6 * C, dtype=torch.float32, device=dev)
         _lib.call("uv_add_rows_f32", _lib.ptr(self.modulation), _lib.ptr(e0_rows), _lib.ptr(tab), n_t, 6 * C,
                   _lib.stream_ptr())                                                               # model.py:239
@@ -208,19 +216,20 @@ class WanAttentionBlock(nn.Module):
         # self-attention (model.py:243-247)
         _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=0, scale_off=C, tid=tid,
                            round_ln=first_block)
-        self.self_attn._self_attn(h, L, grid, freqs, x, tab[:, 2 * C:], tid)
+        self.self_attn._self_attn(h, Ls, grid, freqs, x, tab[:, 2 * C:], tid, batch)
         # cross-attention (model.py:251)
         if self.cross_attn_norm:
             _lib.layernorm_mod(x, h, L, C, self.eps, mode=2, w=self.norm3.weight, b=self.norm3.bias)
         else:
             _lib.call("uv_cast_f32_bf16", _lib.ptr(x), _lib.ptr(h), L * C, _lib.stream_ptr())
+        Lc = ctx.shape[0] // batch
         if "forward" in self.cross_attn.__dict__:
             # forward was re-assigned on the instance (UniVid hook): honour it, then add the residual un-fused
-            y = self.cross_attn.forward(h[:L].unsqueeze(0), ctx.unsqueeze(0), None)
-            y = y[0].contiguous()
+            y = self.cross_attn.forward(h.view(batch, Ls, C), ctx.view(batch, Lc, C), None)
+            y = y.reshape(L, C).contiguous()
             _lib.call("uv_add_bf16_resid", _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), L, C, _lib.stream_ptr())
         else:
-            self.cross_attn._cross_fused(h, ctx, L, ctx.shape[0], x)
+            self.cross_attn._cross_fused(h, ctx, Ls, Lc, x, batch)
         # FFN (model.py:252-255)
         _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=3 * C, scale_off=4 * C, tid=tid)
         mid = torch.empty(L, self.ffn_dim, dtype=BF16, device=dev)
@@ -426,32 +435,41 @@ class WanModel(nn.Module):
         pt, ph, pw = self.patch_size
         C = self.dim
         sp = _lib.stream_ptr
-        outs = []
-        for b, u in enumerate(x):
-            u = u.to(device=dev, dtype=torch.float32).contiguous()
-            cin, F, H, W = u.shape
+        # Samples of identical shape run as ONE stacked pass ([B*L, C] rows: every GEMM / norm kernel sees B*L rows, the
+        # attention kernel gets a batch dimension). Row-wise kernels and per-(sample, head) attention do not mix samples,
+        # so each sample's result is bit-identical to running it alone; the benefit is occupancy (e.g. CFG's cond + uncond
+        # pair: 4320 attention workgroups instead of 2 x 2160 on 512 slots) and weight reuse. Mixed shapes run one by one.
+        xs_in = [u.to(device=dev, dtype=torch.float32).contiguous() for u in x]
+        groups = [list(range(len(xs_in)))] if len({tuple(u.shape) for u in xs_in}) == 1 else [[i] for i in range(len(xs_in))]
+        outs = [None] * len(xs_in)
+        for idx in groups:
+            B = len(idx)
+            cin, F, H, W = xs_in[idx[0]].shape
             Fp, Hp, Wp = F // pt, H // ph, W // pw
             L = Fp * Hp * Wp
             assert L <= seq_len, "sequence longer than seq_len (model.py:453)"
             # patch embedding: im2col -> GEMM, bf16 result stored as the fp32 residual stream (model.py:448-451)
             Kp = self._prep["patch"].w.shape[1]
-            a = torch.empty(L, Kp, dtype=BF16, device=dev)
-            _lib.call("uv_patchify_bf16", _lib.ptr(u), _lib.ptr(a), a.stride(0), cin, F, H, W, pt, ph, pw, Kp, sp())
-            xs = torch.empty(L, C, dtype=torch.float32, device=dev)
+            a = torch.empty(B * L, Kp, dtype=BF16, device=dev)
+            for j, i in enumerate(idx):
+                _lib.call("uv_patchify_bf16", _lib.ptr(xs_in[i]), _lib.ptr(a[j * L:]), a.stride(0), cin, F, H, W, pt, ph, pw, Kp, sp())
+            xs = torch.empty(B * L, C, dtype=torch.float32, device=dev)
             _lib.gemm_bf16(a, self._prep["patch"].w, self._prep["patch"].b, xs, EPI_F32_FROM_BF16)
             # timesteps: distinct values -> rows; token -> row map (padding tokens beyond L are never computed)
-            tb = t[b].to(device=dev, dtype=torch.float32).flatten()[:L]
+            tb = torch.cat([t[i].to(device=dev, dtype=torch.float32).flatten()[:L] for i in idx])
             tvals, inv = torch.unique(tb, return_inverse=True)
             tid = None if tvals.numel() == 1 else inv.to(torch.int32).contiguous()
             e_rows, e0_rows = self._time_rows(tvals.contiguous())
-            ctx = ctx_all[b]
-            for i, blk in enumerate(self.blocks):
-                blk._run(xs, L, e0_rows, tid, (Fp, Hp, Wp), fr, ctx, first_block=(i == 0))
-            yh = self.head._run(xs, L, e_rows, tid)
-            out = torch.empty(self.out_dim, Fp * pt, Hp * ph, Wp * pw, dtype=torch.float32, device=dev)
-            _lib.call("uv_unpatchify_f32", _lib.ptr(yh), yh.stride(0), _lib.ptr(out), self.out_dim, Fp, Hp, Wp, pt, ph, pw,
-                      sp())
-            outs.append(out)
+            ctx = ctx_all[idx[0]] if B == 1 else torch.cat([ctx_all[i] for i in idx], 0)
+            for li, blk in enumerate(self.blocks):
+                blk._run(xs, L, e0_rows, tid, (Fp, Hp, Wp), fr, ctx, first_block=(li == 0), batch=B)
+            yh = self.head._run(xs, B * L, e_rows, tid)
+            for j, i in enumerate(idx):
+                out = torch.empty(self.out_dim, Fp * pt, Hp * ph, Wp * pw, dtype=torch.float32, device=dev)
+                yj = yh[j * L:(j + 1) * L]
+                _lib.call("uv_unpatchify_f32", _lib.ptr(yj), yj.stride(0), _lib.ptr(out), self.out_dim, Fp, Hp, Wp, pt, ph, pw,
+                          sp())
+                outs[i] = out
         return outs
 
     def unpatchify(self, x, grid_sizes):

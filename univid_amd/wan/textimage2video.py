@@ -154,8 +154,15 @@ class WanTI2V:
             temp_ts = base_mask * ts                                                   # :373
             temp_ts = torch.cat([temp_ts, temp_ts.new_ones(seq_len - temp_ts.size(0)) * ts])
             tvec = temp_ts.unsqueeze(0)
-            cond = self.model([latent], t=tvec, context=context, seq_len=seq_len)[0]
-            uncond = self.model([latent], t=tvec, context=context_null, seq_len=seq_len)[0]
+            if "forward" in self.model.__dict__:
+                # model.forward was re-assigned (UniVid's per-forward text-weight counter, model_pipeline.py:1856-1868):
+                # keep the reference's two calls so the counter advances exactly as there
+                cond = self.model([latent], t=tvec, context=context, seq_len=seq_len)[0]
+                uncond = self.model([latent], t=tvec, context=context_null, seq_len=seq_len)[0]
+            else:
+                # cond + uncond as one stacked pass (bit-identical per sample, better occupancy)
+                cond, uncond = self.model([latent, latent], t=torch.cat([tvec, tvec]), context=[context[0], context_null[0]],
+                                          seq_len=seq_len)
             res = sched.step_cfg(cond.unsqueeze(0), uncond.unsqueeze(0), guide_scale, t, latent.unsqueeze(0),
                                  want_noise_pred=record is not None)
             if record is not None:
