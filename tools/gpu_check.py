@@ -273,13 +273,13 @@ def perf_vae():
 
 def perf():
     print("== perf (full-size shapes)")
-    L, C, F = 11440, 3072, 14336
+    L, C, F = int(os.environ.get('GEMM_M', 11440)), 3072, 14336
     a = (torch.randn(L, C, device=dev) * 0.5).to(BF16)
     for (N, K, name) in [(C, C, "qkvo"), (F, C, "ffn0"), (C, F, "ffn2")]:
         w = (torch.randn(N, K, device=dev) * 0.02).to(BF16)
         aa = a if K == C else (torch.randn(L, K, device=dev) * 0.5).to(BF16)
         out = torch.empty(L, N, dtype=BF16, device=dev)
-        for cfg in (0, 1, 2, 3, 4):
+        for cfg in (0, 4, 5, 6):
             ms = timeit(lambda: _lib.gemm_bf16(aa, w, None, out, EPI_BF16, tile_cfg=cfg))
             print(f"  gemm {name} M{L} N{N} K{K} cfg{cfg}: {ms:.3f} ms  {2 * L * N * K / ms / 1e9:.1f} TFLOP/s", flush=True)
     H, D = 24, 128

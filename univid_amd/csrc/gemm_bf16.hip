@@ -54,9 +54,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
     constexpr int A_BYTES = BM * 128;
     constexpr int W_BYTES = BN * 128;
     constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    constexpr int A_INSTR = BM / 8 / NW;  // glds wave-instructions per wave for the A tile
-    constexpr int W_INSTR = BN / 8 / NW;
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+    constexpr int A_INSTR = (BM / 8 + NW - 1) / NW;  // glds wave-instructions per wave for the A tile
+    constexpr int W_INSTR = (BN / 8 + NW - 1) / NW;  // (the last pass may cover only part of the waves: guarded below)
+    static_assert(BM % 8 == 0 && BN % 8 == 0 && (BM / WM) % 16 == 0 && (BN / WN) % 16 == 0, "tile/wave mismatch");
     constexpr bool TRANS = (EPI == UV_EPI_BF16_T);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,10 +110,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
         const int koff = kt * UV_BK;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i)
-            glds16(a_src[i] + koff, (lds_void*)(base + (i * NW + wave) * 1024));
+            if ((i * NW + wave) * 8 < BM) glds16(a_src[i] + koff, (lds_void*)(base + (i * NW + wave) * 1024));
 #pragma unroll
         for (int i = 0; i < W_INSTR; ++i)
-            glds16(w_src[i] + koff, (lds_void*)(base + A_BYTES + (i * NW + wave) * 1024));
+            if ((i * NW + wave) * 8 < BN) glds16(w_src[i] + koff, (lds_void*)(base + A_BYTES + (i * NW + wave) * 1024));
     };
 
     f32x4 acc[TN][TM];
@@ -312,13 +312,18 @@ extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw,
             const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
             // cost ~ rounds x tile area; 256x192 tiles carry 3/4 of the work of 256x256 at slightly lower efficiency
             const double c256 = (double)((t256 + 255) / 256) * 1.00, c192 = (double)((t192 + 255) / 256) * 0.78;
-            if (N % 192 == 0 && c192 < c256) return launch_cfg<256, 192, 2, 4>(a, epilogue, s);
-            return launch_cfg<256, 256, 2, 4>(a, epilogue, s);
+            // 16 waves per workgroup (64x64 / 64x48 per wave, 4 waves per SIMD): more waves to hide the LDS and DMA
+            // latency than the 8-wave layout (measured +6 % on the ffn.0 shape)
+            // long-K shapes (ffn.2, K = 14336) stream A once per n-tile: the wider tile wins there despite worse quantisation
+            if (N % 192 == 0 && c192 < c256 && K <= 4096) return launch_cfg<256, 192, 4, 4>(a, epilogue, s);
+            return launch_cfg<256, 256, 4, 4>(a, epilogue, s);
         }
         case 1: return launch_cfg<128, 128, 2, 2>(a, epilogue, s);
         case 2: return launch_cfg<256, 256, 2, 4>(a, epilogue, s);
         case 3: return launch_cfg<256, 128, 4, 2>(a, epilogue, s);
         case 4: return launch_cfg<256, 192, 2, 4>(a, epilogue, s);
+        case 5: return launch_cfg<256, 256, 4, 4>(a, epilogue, s);
+        case 6: return launch_cfg<256, 192, 4, 4>(a, epilogue, s);
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown tile_cfg %d", tile_cfg);
             return -1;
