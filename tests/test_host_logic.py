@@ -166,3 +166,28 @@ def test_shard_range_partitions_the_batch():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_checkpoint_roundtrip_diffusers_layout(tmp_path):
+    """config.json + (sharded) safetensors: what WanModel.from_pretrained reads in the reference (textimage2video.py:103)."""
+    from univid_amd.wan import checkpoint
+    m = WanModel(model_type="ti2v", in_dim=48, out_dim=48, dim=256, ffn_dim=512, num_heads=4, num_layers=2, text_len=32, text_dim=64)
+    detinit.init_module_(m, 5)
+    for name, shard in (("single", 1 << 40), ("sharded", 1 << 20)):
+        d = tmp_path / name
+        checkpoint.save_wan_model(m, str(d), max_shard_bytes=shard)
+        files = sorted(os.listdir(d))
+        assert "config.json" in files
+        assert ("diffusion_pytorch_model.safetensors.index.json" in files) == (name == "sharded")
+        m2 = WanModel.from_pretrained(str(d))
+        assert m2.num_layers == 2 and m2.patch_size == (1, 2, 2) and m2.model_type == "ti2v"
+        sd, sd2 = m.state_dict(), m2.state_dict()
+        assert sd.keys() == sd2.keys() and all(torch.equal(sd[k], sd2[k]) for k in sd)
+    import json
+    bad = tmp_path / "bad"
+    checkpoint.save_wan_model(m, str(bad))
+    cfg = json.load(open(bad / "config.json"))
+    cfg["num_layers"] = 3
+    json.dump(cfg, open(bad / "config.json", "w"))
+    with pytest.raises(RuntimeError, match="does not match"):
+        WanModel.from_pretrained(str(bad))

@@ -492,6 +492,13 @@ class WanModel(nn.Module):
         return self
 
     @classmethod
+    def from_pretrained(cls, checkpoint_dir, subfolder=None, device="cpu"):
+        """diffusers-layout directory (config.json + [sharded] safetensors), as the reference's ModelMixin.from_pretrained
+        (models/wan/textimage2video.py:103)."""
+        from .checkpoint import load_wan_model
+        return load_wan_model(checkpoint_dir, device=device, subfolder=subfolder)
+
+    @classmethod
     def from_config(cls, cfg: dict):
         keys = ("model_type", "patch_size", "text_len", "in_dim", "dim", "ffn_dim", "freq_dim", "text_dim", "out_dim",
                 "num_heads", "num_layers", "window_size", "qk_norm", "cross_attn_norm", "eps")
