@@ -517,6 +517,29 @@ def test_vae_bf16x3_precision_mode():
         assert not torch.equal(fast.decode([g["dec_in_0"].to(DEV)])[0], exact.decode([g["dec_in_0"].to(DEV)])[0])
 
 
+def test_vae_full_width_vs_oracle():
+    """The production VAE widths (encoder 160..640, decoder 1024..256 channels, z = 48) on a small clip, fp32 mode and
+    bf16x3 mode, against the CPU oracle run here."""
+    from oracle import wan_vae
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    cfg = wan_vae.FULL_CFG
+    sd = wan_vae.make_state_dict(cfg, 2)
+    ora = wan_vae.WanVAE(sd, cfg)
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(48, 2, 2, 3, generator=g)
+    vid = torch.tanh(torch.randn(3, 5, 32, 48, generator=g))
+    with torch.no_grad():
+        ref_dec = wan_vae.vae_decode(ora, [z])[0]
+        ref_enc = wan_vae.vae_encode(ora, [vid])[0]
+    for prec in ("fp32", "bf16x3"):
+        vae = Wan2_2_VAE(device=DEV, precision=prec)
+        vae.model.load_state_dict(sd)
+        with torch.no_grad():
+            assert_f32_close(vae.decode([z.to(DEV)])[0], ref_dec, name=f"full-width decode {prec}")
+            assert_f32_close(vae.encode([vid.to(DEV)])[0], ref_enc, name=f"full-width encode {prec}")
+
+
 def test_conv3d_kernel_geometries():
     """Every convolution geometry the VAE uses, against F.conv3d / F.conv2d."""
     import torch.nn.functional as F

@@ -25,14 +25,16 @@ print(f"attention L{L}: {ms:.3f} ms {4*L*L*C/ms/1e9:.1f} TFLOP/s")
 if os.environ.get("STAMPS"):
     import ctypes
     lib = _lib.load()
-    for nw in (4, 8):
+    for nw, extra in ((4, 0), (8, 0), (4, 40000)):
         nblk = ((L + nw * 32 - 1) // (nw * 32)) * H
         st = torch.zeros(nblk * nw * 5, dtype=torch.int64, device=dev)
         fn = lib.uvdbg_flash_attn_stamps
-        fn.argtypes = [ctypes.c_void_p, ctypes.c_long] * 3 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_long] * 3 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         for _ in range(2):
-            rc = fn(q.data_ptr(), C, k.data_ptr(), C, vt.data_ptr(), vt.stride(0), out.data_ptr(), C, L, L, H, 1 / math.sqrt(D), nw, st.data_ptr(), None)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize(); import time; t0 = time.time()
+            rc = fn(q.data_ptr(), C, k.data_ptr(), C, vt.data_ptr(), vt.stride(0), out.data_ptr(), C, L, L, H, 1 / math.sqrt(D), nw, st.data_ptr(), extra, None)
+            torch.cuda.synchronize(); dt = time.time() - t0
+        print(f"nw={nw} extra_lds={extra}: wall {dt*1e3:.2f} ms")
         v = st.view(-1, 5).double()
         tiles = (L + 63) // 64
         per = v.median(0).values / tiles

@@ -329,15 +329,20 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
 // forbid overlaps the real kernel has: read the SHARES, never its run time.
 extern "C" int uvdbg_flash_attn_stamps(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out,
                                        long ldo, int Lq, int Lk, int H, float softmax_scale, int nw,
-                                       unsigned long long* stamps, void* stream) {
+                                       unsigned long long* stamps, int extra_lds, void* stream) {
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
     a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = 1;
     a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
     const dim3 grid(a.q_blocks * H), block(nw * 64);
-    if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
-    else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
+    // extra_lds: unused dynamic LDS, only to cap the number of co-resident workgroups per CU in occupancy experiments
+    if (extra_lds > 0) {
+        hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<128, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+        hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<128, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+    }
+    if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8, true>), grid, block, extra_lds, (hipStream_t)stream, a, stamps);
+    else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true>), grid, block, extra_lds, (hipStream_t)stream, a, stamps);
     UV_CHECK_LAUNCH("uvdbg_flash_attn_stamps");
     return 0;
 }
