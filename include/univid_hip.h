@@ -116,15 +116,17 @@ int uv_conv3d_f32(const float* in, long ld_in, int Tin, int Hin, int Win, const 
                   long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw,
                   int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr, void* stream);
 /* The same convolution in split-bf16 ("bf16x3") arithmetic: x*w ~ xh*wh + xh*wl + xl*wh on the bf16 MFMA with f32 accumulate
- * (relative error per product ~1e-5; up to 16/3 x the f32-MFMA rate). w_split comes from uv_split_weights_bf16x3. */
+ * (relative error per product ~1e-5; up to 16/3 x the f32-MFMA rate). w_split comes from uv_split_weights_bf16x3.
+ * in_split=1: the input ring already holds split activations ([C/32][32 hi | 32 lo] bf16 per pixel, as written by
+ * uv_vae_rms_silu(split_out=1)); in_split=0: f32 activations, split in registers. */
 int uv_conv3d_bf16x3(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w_split, const float* bias, float* out,
                      long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw,
-                     int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr, void* stream);
+                     int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr, int in_split, void* stream);
 /* w [n] f32 (rows of K, K % 32 == 0) -> [n/32][32 hi | 32 lo] bf16 with hi = bf16(w), lo = bf16(w - hi) */
 int uv_split_weights_bf16x3(const float* w, void* out, long n, void* stream);
 /* y = x / max(||x||,1e-12) * sqrt(C) * gamma [-> SiLU] per pixel (RMS_norm + SiLU, vae2_2.py:45-59, 201-206) */
 int uv_vae_rms_silu(const float* in, long ld_in, const float* gamma, float* out, long ld_out, long P, int C, int do_silu,
-                    void* stream);
+                    int split_out, void* stream);
 /* in-place row softmax of x*scale (AttentionBlock's SDPA, vae2_2.py:267-271) */
 int uv_softmax_rows_f32(float* x, long ld, int R, int n, float scale, void* stream);
 /* out += DupUp3D(x) (vae2_2.py:390-412); out += AvgDown3D(x) (vae2_2.py:335-367) */

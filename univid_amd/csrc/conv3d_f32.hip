@@ -41,6 +41,8 @@ struct ConvArgs {
 //         bf16 rounding of lo), i.e. ~100x below the 1e-3 tolerance, at up to 16/3 x the f32-MFMA rate. Weights are
 //         pre-split on the host into [Cout][K/32][32 hi | 32 lo] bf16 (same bytes per row as f32, so the staging code
 //         is shared); activations stay f32 in HBM/LDS and are split in registers.
+// PREC 2: bf16x3 with the ACTIVATIONS pre-split too (the producer, uv_vae_rms_silu, writes [C/32][32 hi | 32 lo] bf16 into
+//         the input ring: same bytes per pixel as f32): no conversion work in the MFMA loop at all.
 template <int BM, int BN, int WM, int WN, int PREC>
 __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
     constexpr int NW = WM * WN;
@@ -156,6 +158,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
             bf16x8 ah[TM], al[TM], wh[TN], wl[TN];
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
+                if (PREC == 2) {
+                    ah[j] = *(const bf16x8*)(base + a_off[j] + ((fq ^ a_key[j]) << 4));
+                    al[j] = *(const bf16x8*)(base + a_off[j] + (((4 + fq) ^ a_key[j]) << 4));
+                    continue;
+                }
                 const f32x4 x0 = *(const f32x4*)(base + a_off[j] + (((2 * fq) ^ a_key[j]) << 4));
                 const f32x4 x1 = *(const f32x4*)(base + a_off[j] + (((2 * fq + 1) ^ a_key[j]) << 4));
 #pragma unroll
@@ -255,13 +262,20 @@ static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, c
     a.t_off = t_off; a.ph = ph; a.pw = pw; a.up = up; a.interleave = interleave;
     a.M = Tout * Hout * Wout;
     hipStream_t s = (hipStream_t)stream;
+    // tile choice: 256x256 (16 waves, 4 per SIMD) when Cout >= 256 and the grid still fills the chip: halves the A gather
+    // per output; 256x128 (8 waves) next; the 4-wave 128x128 tile for the low-resolution stages
+    const long t256 = (long)((a.M + 255) / 256) * ((Cout + 255) / 256);
+    const long t128 = (long)((a.M + 255) / 256) * ((Cout + 127) / 128);
     if (prec == 0) {
         launch_conv<128, 128, 2, 2, 0>(a, s);
-    } else {
-        // big tile (8 waves) once it fills the chip, else the 4-wave tile for the low-resolution stages
-        const long big = (long)((a.M + 255) / 256) * ((Cout + 127) / 128);
-        if (big >= 256) launch_conv<256, 128, 4, 2, 1>(a, s);
+    } else if (prec == 1) {
+        if (Cout >= 256 && t256 >= 256) launch_conv<256, 256, 4, 4, 1>(a, s);
+        else if (t128 >= 256) launch_conv<256, 128, 4, 2, 1>(a, s);
         else launch_conv<128, 128, 2, 2, 1>(a, s);
+    } else {
+        if (Cout >= 256 && t256 >= 256) launch_conv<256, 256, 4, 4, 2>(a, s);
+        else if (t128 >= 256) launch_conv<256, 128, 4, 2, 2>(a, s);
+        else launch_conv<128, 128, 2, 2, 2>(a, s);
     }
     UV_CHECK_LAUNCH("uv_conv3d");
     return 0;
@@ -276,12 +290,14 @@ extern "C" int uv_conv3d_f32(const float* in, long ld_in, int Tin, int Hin, int 
 }
 
 // Same convolution with split-bf16 (3-pass) arithmetic. w_split: [Cout][K/32][32 hi | 32 lo] bf16 (uv_split_weights_bf16x3).
+// in_split = 1: `in` already holds split activations ([C/32][32 hi | 32 lo] bf16 per pixel, written by uv_vae_rms_silu with
+// split_out = 1; ld_in still counted in f32-sized elements = channels).
 extern "C" int uv_conv3d_bf16x3(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w_split,
                                 const float* bias, float* out, long ldo, int Tout, int Hout, int Wout, int Cin, int Cout,
                                 int kt, int kh, int kw, int st, int sh, int sw, int t_off, int ph, int pw, int up,
-                                int interleave, const float* resid, long ldr, void* stream) {
+                                int interleave, const float* resid, long ldr, int in_split, void* stream) {
     return conv_common(in, ld_in, Tin, Hin, Win, w_split, bias, out, ldo, Tout, Hout, Wout, Cin, Cout, kt, kh, kw, st, sh, sw,
-                       t_off, ph, pw, up, interleave, resid, ldr, 1, stream);
+                       t_off, ph, pw, up, interleave, resid, ldr, in_split ? 2 : 1, stream);
 }
 
 // w [rows][K] f32 (K % 32 == 0) -> [rows][K/32][32 hi | 32 lo] bf16, hi = bf16(w), lo = bf16(w - hi)

@@ -8,9 +8,11 @@
 #include "common.h"
 
 // y = x / max(||x||_2, 1e-12) * sqrt(C) * gamma  [-> SiLU]      (F.normalize(x, dim=C) * scale * gamma)
+// split_out: write each value as bf16 hi + bf16 lo in the [C/32][32 hi | 32 lo] layout uv_conv3d_bf16x3(in_split=1) reads
+// (same bytes per pixel as f32).
 template <int MAXV>
 __global__ __launch_bounds__(256) void vae_rms_silu_kernel(const float* in, long ld_in, const float* gamma, float* out,
-                                                          long ld_out, long P, int C, int do_silu) {
+                                                          long ld_out, long P, int C, int do_silu, int split_out) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= P) return;
@@ -40,18 +42,29 @@ __global__ __launch_bounds__(256) void vae_rms_silu_kernel(const float* in, long
                 if (do_silu) t = silu_f32(t);
                 y[e] = t;
             }
-            *(f32x4*)(out + row * ld_out + c4 * 4) = y;
+            if (split_out) {
+                const int c = c4 * 4;
+                bf16_t* ob = (bf16_t*)(out + row * ld_out) + (c >> 5) * 64 + (c & 31);
+                float lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lo[e] = y[e] - round_bf(y[e]);
+                *(u32x2*)ob = (u32x2){pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+                *(u32x2*)(ob + 32) = (u32x2){pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3])};
+            } else {
+                *(f32x4*)(out + row * ld_out + c4 * 4) = y;
+            }
         }
     }
 }
 
 extern "C" int uv_vae_rms_silu(const float* in, long ld_in, const float* gamma, float* out, long ld_out, long P, int C,
-                               int do_silu, void* stream) {
+                               int do_silu, int split_out, void* stream) {
     UV_CHECK_ARG(in && gamma && out && P > 0, "uv_vae_rms_silu: bad arguments");
+    UV_CHECK_ARG(!split_out || C % 32 == 0, "uv_vae_rms_silu: split output needs C %% 32 == 0 (C=%d)", C);
     UV_CHECK_ARG(C % 4 == 0 && C <= 2048 && ld_in % 4 == 0 && ld_out % 4 == 0, "uv_vae_rms_silu: C=%d unsupported", C);
     const dim3 grid((unsigned)((P + 3) / 4)), block(256);
-    if (C <= 512) hipLaunchKernelGGL(vae_rms_silu_kernel<2>, grid, block, 0, (hipStream_t)stream, in, ld_in, gamma, out, ld_out, P, C, do_silu);
-    else hipLaunchKernelGGL(vae_rms_silu_kernel<8>, grid, block, 0, (hipStream_t)stream, in, ld_in, gamma, out, ld_out, P, C, do_silu);
+    if (C <= 512) hipLaunchKernelGGL(vae_rms_silu_kernel<2>, grid, block, 0, (hipStream_t)stream, in, ld_in, gamma, out, ld_out, P, C, do_silu, split_out);
+    else hipLaunchKernelGGL(vae_rms_silu_kernel<8>, grid, block, 0, (hipStream_t)stream, in, ld_in, gamma, out, ld_out, P, C, do_silu, split_out);
     UV_CHECK_LAUNCH("uv_vae_rms_silu");
     return 0;
 }

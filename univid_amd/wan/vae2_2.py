@@ -214,24 +214,27 @@ class _Engine:
 
     # -- kernels --
     def _conv(self, op, src, Tin, Hin, Win, Tout, Hout, Wout, st=1, sh=1, sw=1, t_off=0, ph=0, pw=0, up=0, interleave=0,
-              resid=None, out=None, ldo=None):
+              resid=None, out=None, ldo=None, in_split=False):
         cout = op.cout // 2 if interleave else op.cout
         tt = Tout * 2 if interleave else Tout
         if out is None:
             out = torch.empty(tt, Hout, Wout, cout, dtype=torch.float32, device=self.dev)
             ldo = cout
-        fast = self.precision == "bf16x3"
-        _lib.call("uv_conv3d_bf16x3" if fast else "uv_conv3d_f32", _lib.ptr(src), src.stride(-2), Tin, Hin, Win,
-                  _lib.ptr(op.split() if fast else op.w), _lib.ptr(op.b), _lib.ptr(out),
-                  ldo, Tout, Hout, Wout, op.cin_pad, op.cout, op.kt, op.kh, op.kw, st, sh, sw, t_off, ph, pw, up, interleave,
-                  _lib.ptr(resid), 0 if resid is None else resid.stride(-2), _lib.stream_ptr(),
-                  flops=2 * Tout * Hout * Wout * op.cout * op.kt * op.kh * op.kw * op.cin)
+        flops = 2 * Tout * Hout * Wout * op.cout * op.kt * op.kh * op.kw * op.cin
+        geom = (ldo, Tout, Hout, Wout, op.cin_pad, op.cout, op.kt, op.kh, op.kw, st, sh, sw, t_off, ph, pw, up, interleave,
+                _lib.ptr(resid), 0 if resid is None else resid.stride(-2))
+        if self.precision == "bf16x3":
+            _lib.call("uv_conv3d_bf16x3", _lib.ptr(src), src.stride(-2), Tin, Hin, Win, _lib.ptr(op.split()), _lib.ptr(op.b),
+                      _lib.ptr(out), *geom, int(in_split), _lib.stream_ptr(), flops=flops)
+        else:
+            _lib.call("uv_conv3d_f32", _lib.ptr(src), src.stride(-2), Tin, Hin, Win, _lib.ptr(op.w), _lib.ptr(op.b),
+                      _lib.ptr(out), *geom, _lib.stream_ptr(), flops=flops)
         return out
 
-    def _rms_silu(self, x, gamma, out, silu=True):
+    def _rms_silu(self, x, gamma, out, silu=True, split=False):
         P = x.numel() // x.shape[-1]
         _lib.call("uv_vae_rms_silu", _lib.ptr(x), x.stride(-2), _lib.ptr(gamma), _lib.ptr(out), out.stride(-2), P, x.shape[-1],
-                  int(silu), _lib.stream_ptr())
+                  int(silu), int(split), _lib.stream_ptr())
 
     def _pointwise(self, op, x, resid=None):
         """1x1(x1) convolution = fp32 GEMM over pixel rows."""
@@ -242,12 +245,13 @@ class _Engine:
         return out
 
     # -- blocks --
-    def causal_conv(self, conv, x_into_ring, T, H, W, tmax, resid=None):
-        """3x3x3 causal conv over the ring [cache(2) | T frames]; `x_into_ring(dst)` fills the current frames."""
+    def causal_conv(self, conv, x_into_ring, T, H, W, tmax, resid=None, in_split=False):
+        """3x3x3 causal conv over the ring [cache(2) | T frames]; `x_into_ring(dst)` fills the current frames.
+        in_split: the filler writes split-bf16 activations (bf16x3 mode; zeros stay zeros, so the cache logic is unchanged)."""
         op = self.ops[conv]
         ring = op.ring(H, W, tmax)
         x_into_ring(ring[CACHE_T:CACHE_T + T])
-        y = self._conv(op, ring, CACHE_T + T, H, W, T, H, W, t_off=0, ph=1, pw=1, resid=resid)
+        y = self._conv(op, ring, CACHE_T + T, H, W, T, H, W, t_off=0, ph=1, pw=1, resid=resid, in_split=in_split)
         _shift(ring, T)
         return y
 
@@ -256,8 +260,10 @@ class _Engine:
         T, H, W, C = x.shape
         res = blk.residual
         h = x if isinstance(blk.shortcut, nn.Identity) else self._pointwise(self.ops[blk.shortcut], x)
-        y = self.causal_conv(res[2], lambda dst: self._rms_silu(x, res[0].gamma, dst), T, H, W, tmax)
-        return self.causal_conv(res[6], lambda dst: self._rms_silu(y, res[3].gamma, dst), T, H, W, tmax, resid=h)
+        sp = self.precision == "bf16x3" and C % 32 == 0 and blk.out_dim % 32 == 0
+        y = self.causal_conv(res[2], lambda dst: self._rms_silu(x, res[0].gamma, dst, split=sp), T, H, W, tmax, in_split=sp)
+        return self.causal_conv(res[6], lambda dst: self._rms_silu(y, res[3].gamma, dst, split=sp), T, H, W, tmax, resid=h,
+                                in_split=sp)
 
     def attention(self, blk, x):
         """AttentionBlock.forward vae2_2.py:255-277: per-frame single-head attention, head_dim = C, fp32."""
@@ -338,7 +344,9 @@ class _Engine:
         x = self.attention(enc.middle[1], x)
         x = self.resblock(enc.middle[2], x, tmax)
         T2, H2, W2, _ = x.shape
-        return self.causal_conv(enc.head[2], lambda dst: self._rms_silu(x, enc.head[0].gamma, dst), T2, H2, W2, tmax)
+        sp = self.precision == "bf16x3" and x.shape[-1] % 32 == 0
+        return self.causal_conv(enc.head[2], lambda dst: self._rms_silu(x, enc.head[0].gamma, dst, split=sp), T2, H2, W2, tmax,
+                                in_split=sp)
 
     def decoder_chunk(self, xin, first_chunk):
         """xin: [1, h, w, z] rows of conv2's output for one latent frame -> [T, 8h, 8w, 12]."""
@@ -364,7 +372,9 @@ class _Engine:
                 tmax *= ft
             x = xm
         T, Hh, Ww, _ = x.shape
-        return self.causal_conv(dec.head[2], lambda dst: self._rms_silu(x, dec.head[0].gamma, dst), T, Hh, Ww, tmax)
+        sp = self.precision == "bf16x3" and x.shape[-1] % 32 == 0
+        return self.causal_conv(dec.head[2], lambda dst: self._rms_silu(x, dec.head[0].gamma, dst, split=sp), T, Hh, Ww, tmax,
+                                in_split=sp)
 
 
 class WanVAE_(nn.Module):
