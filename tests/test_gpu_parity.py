@@ -283,6 +283,41 @@ def test_dit_tiny_forward_vs_golden():
     assert torch.equal(t1d, one), "t of shape [B] must equal the expanded [B, seq_len] form"
 
 
+def test_attention_modules_reference_signatures():
+    """WanSelfAttention.forward(x, seq_lens, grid_sizes, freqs) / WanCrossAttention.forward(x, context, None) as standalone
+    modules (the signatures UniVid's hooks and the reference's SP patch call, model.py:126-180)."""
+    from oracle import wan_dit
+    from univid_amd import detinit
+    from univid_amd.wan.model import WanCrossAttention, WanSelfAttention, rope_params
+    dim, heads, grid = 256, 2, (2, 5, 7)
+    Lt = 70
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(1, Lt + 6, dim, generator=g)                      # 6 padding tokens: masked as keys (k_lens = seq_lens)
+    ctx = (torch.randn(1, 32, dim, generator=g) * 0.5).to(BF16)
+    d = dim // heads
+    freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)), rope_params(1024, 2 * (d // 6))], dim=1)
+    for cls, prefix in ((WanSelfAttention, "blocks.0.self_attn."), (WanCrossAttention, "blocks.0.cross_attn.")):
+        with torch.device(DEV):
+            mod = cls(dim, heads, (-1, -1), True, 1e-6)
+        sd = {prefix + k: v for k, v in mod.state_dict(keep_vars=True).items()}
+        detinit.init_state_dict_(sd, 4)
+        sdc = {k: v.detach().cpu() for k, v in sd.items()}
+        with torch.no_grad():
+            if cls is WanSelfAttention:
+                got = mod(x.to(DEV), torch.tensor([Lt]), torch.tensor([grid]), freqs)
+                ref = wan_dit.self_attention(sdc, prefix, x, torch.tensor([Lt]), torch.tensor([grid]), freqs, heads, 1e-6)
+                got, ref = got[:, :Lt], ref[:, :Lt]                    # outputs of padding queries are don't-care
+            else:
+                got = mod(x.to(DEV), ctx.to(DEV), None)
+                ref = wan_dit.cross_attention(sdc, prefix, x, ctx, heads, 1e-6)
+        assert got.dtype == BF16 and got.shape == ref.shape
+        # composite op (3 GEMMs + norm + attention + GEMM): bf16 rounding flips of the attention output are mixed by
+        # the o projection, so gate on the relative rms error and the max error instead of per-element ulps
+        d = got.float().cpu() - ref.float()
+        assert d.pow(2).mean().sqrt() <= 4e-3 * ref.float().pow(2).mean().sqrt(), cls.__name__
+        assert d.abs().max() <= 2e-2 * ref.float().abs().max(), cls.__name__
+
+
 def test_dit_batched_forward_is_bit_identical_to_sequential():
     """Samples of equal shape run as one stacked pass (the CFG cond/uncond pair in WanTI2V.denoise): per-sample results
     must not change by a single bit; mixed shapes fall back to one-by-one."""
