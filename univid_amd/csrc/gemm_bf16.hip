@@ -45,7 +45,65 @@ __device__ __forceinline__ void glds16(const void* g, lds_void* l) {
     __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+// One 16x16 accumulator fragment through the fused epilogue. Plain product (D = Wfrag x Afrag): the lane holds
+// n = nb + 4*fq + {0..3} for m = mb + frow. Transposed product (EPI_BF16_T, D = Afrag x Wfrag): m = mb + 4*fq + {0..3}
+// for n = nb + frow.
+template <int EPI>
+__device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, const f32x4& a, int frow, int fq) {
+    if (EPI != UV_EPI_BF16_T) {
+        const int m = mb + frow, n = nb + 4 * fq;
+        if (m >= p.M || n >= p.N) return;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a[e];
+        if (p.bias) {
+            const u32x2 bb = *(const u32x2*)(p.bias + n);
+            v[0] += bf2f((bf16_t)(bb[0] & 0xffff));
+            v[1] += bf2f((bf16_t)(bb[0] >> 16));
+            v[2] += bf2f((bf16_t)(bb[1] & 0xffff));
+            v[3] += bf2f((bf16_t)(bb[1] >> 16));
+        }
+        if (EPI == UV_EPI_BF16) {
+            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + n) = o;
+        } else if (EPI == UV_EPI_GELU_BF16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f32(round_bf(v[e]));
+            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + n) = o;
+        } else if (EPI == UV_EPI_F32_FROM_BF16) {
+            f32x4 o = {round_bf(v[0]), round_bf(v[1]), round_bf(v[2]), round_bf(v[3])};
+            *(f32x4*)((float*)p.out + (long)m * p.ldo + n) = o;
+        } else if (EPI == UV_EPI_RESID_F32) {
+            float* xp = (float*)p.out + (long)m * p.ldo + n;
+            f32x4 x = *(const f32x4*)xp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = __fadd_rn(x[e], round_bf(v[e]));
+            *(f32x4*)xp = x;
+        } else if (EPI == UV_EPI_GATE_RESID_F32) {
+            const int t = p.gate_tid ? p.gate_tid[m] : 0;
+            const f32x4 g = *(const f32x4*)(p.gate + (long)t * p.gate_stride + n);
+            float* xp = (float*)p.out + (long)m * p.ldo + n;
+            f32x4 x = *(const f32x4*)xp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = __fadd_rn(x[e], __fmul_rn(round_bf(v[e]), g[e]));
+            *(f32x4*)xp = x;
+        }
+    } else {
+        const int n = nb + frow, m = mb + 4 * fq;
+        if (n >= p.N || m >= p.M) return;  // M is padded to a multiple of 4 by the caller's ldo
+        const float b = p.bias ? bf2f(p.bias[n]) : 0.f;
+        bf16_t* op = (bf16_t*)p.out + (long)n * p.ldo + m;
+        if (m + 3 < p.M) {
+            u32x2 o = {pack_bf2(a[0] + b, a[1] + b), pack_bf2(a[2] + b, a[3] + b)};
+            *(u32x2*)op = o;
+        } else {
+            for (int e = 0; e < 4 && m + e < p.M; ++e) op[e] = f2bf(a[e] + b);
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int NS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int NT = NW * 64;
@@ -141,14 +199,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
     }
 
     const int nk = p.K / UV_BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const char* base = smem + buf * STAGE_BYTES;
+    auto compute = [&](const char* base) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[TM], wf[TN];
@@ -169,97 +220,252 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
                 }
         }
+    };
+    if constexpr (NS == 2) {
+        // two LDS stages: the DMA of tile kt+1 overlaps the MFMAs of tile kt, one vmcnt(0) + barrier per K tile
+        stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+            compute(smem + buf * STAGE_BYTES);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        // NS-deep ring for launches that run ~one workgroup per CU (the leftover-row strip of a split GEMM, small-M
+        // projections): NS-1 K tiles stay in flight across raw barriers, the only VMEM wait is a counted vmcnt.
+        // After barrier kt every wave has finished the MFMAs of tile kt-1, so its buffer can take tile kt+NS-1.
+        static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "ring variant needs unguarded staging");
+        constexpr int LPS = A_INSTR + W_INSTR;  // DMA instructions per thread per K tile
+        static_assert((NS - 2) * LPS < 64, "vmcnt range");
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0)
+            if (s0 < nk) stage(s0, s0);
+        int buf = 0, nbuf = NS - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + NS - 2 < nk) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kt + NS - 1 < nk) stage(kt + NS - 1, nbuf);
+            compute(smem + buf * STAGE_BYTES);
+            buf = buf + 1 == NS ? 0 : buf + 1;
+            nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
+        }
     }
 
     // ---- epilogue
-    if (!TRANS) {
-        // lane holds n = nb + 4*fq + {0..3} for m = mb + frow
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int m = m0 + wm * (BM / WM) + j * 16 + frow;
-            if (m >= p.M) continue;
-            const float* grow = nullptr;
-            if (EPI == UV_EPI_GATE_RESID_F32) {
-                const int t = p.gate_tid ? p.gate_tid[m] : 0;
-                grow = p.gate + (long)t * p.gate_stride;
-            }
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const int n = n0 + wn * (BN / WN) + i * 16 + 4 * fq;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
-                if (p.bias) {
-                    const u32x2 bb = *(const u32x2*)(p.bias + n);
-                    v[0] += bf2f((bf16_t)(bb[0] & 0xffff));
-                    v[1] += bf2f((bf16_t)(bb[0] >> 16));
-                    v[2] += bf2f((bf16_t)(bb[1] & 0xffff));
-                    v[3] += bf2f((bf16_t)(bb[1] >> 16));
-                }
-                if (EPI == UV_EPI_BF16) {
-                    u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                    *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + n) = o;
-                } else if (EPI == UV_EPI_GELU_BF16) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f32(round_bf(v[e]));
-                    u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                    *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + n) = o;
-                } else if (EPI == UV_EPI_F32_FROM_BF16) {
-                    f32x4 o = {round_bf(v[0]), round_bf(v[1]), round_bf(v[2]), round_bf(v[3])};
-                    *(f32x4*)((float*)p.out + (long)m * p.ldo + n) = o;
-                } else if (EPI == UV_EPI_RESID_F32) {
-                    float* xp = (float*)p.out + (long)m * p.ldo + n;
-                    f32x4 x = *(const f32x4*)xp;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = __fadd_rn(x[e], round_bf(v[e]));
-                    *(f32x4*)xp = x;
-                } else if (EPI == UV_EPI_GATE_RESID_F32) {
-                    float* xp = (float*)p.out + (long)m * p.ldo + n;
-                    f32x4 x = *(const f32x4*)xp;
-                    const f32x4 g = *(const f32x4*)(grow + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = __fadd_rn(x[e], __fmul_rn(round_bf(v[e]), g[e]));
-                    *(f32x4*)xp = x;
-                }
-            }
-        }
-    } else {
-        // transposed product: lane holds m = mb + 4*fq + {0..3} for n = nb + frow
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int n = n0 + wn * (BN / WN) + i * 16 + frow;
-            if (n >= p.N) continue;
-            const float b = p.bias ? bf2f(p.bias[n]) : 0.f;
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                const int m = m0 + wm * (BM / WM) + j * 16 + 4 * fq;
-                if (m >= p.M) continue;  // M is padded to a multiple of 4 by the caller's ldo
-                bf16_t* op = (bf16_t*)p.out + (long)n * p.ldo + m;
-                if (m + 3 < p.M) {
-                    u32x2 o = {pack_bf2(acc[i][j][0] + b, acc[i][j][1] + b),
-                               pack_bf2(acc[i][j][2] + b, acc[i][j][3] + b)};
-                    *(u32x2*)op = o;
-                } else {
-                    for (int e = 0; e < 4 && m + e < p.M; ++e) op[e] = f2bf(acc[i][j][e] + b);
-                }
-            }
-        }
-    }
+        for (int i = 0; i < TN; ++i)
+            epi_frag<EPI>(p, m0 + wm * (BM / WM) + j * 16, n0 + wn * (BN / WN) + i * 16, acc[i][j], frow, fq);
 }
 
-template <int BM, int BN, int WM, int WN>
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves in two groups that run half a phase apart ("ping-pong"): while one group issues its 16 MFMAs
+// of a phase, the other group (the second wave of every SIMD) reads its fragments from LDS and issues the LDS-DMA of a
+// later half-tile. The K tile is staged as four 16-KiB half-tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255), one
+// per phase, and stays in flight across the barriers: the only VMEM wait in the loop is a counted vmcnt(6) once per K
+// tile. A wave owns the output rows {128*h + 64*wr + 0..63} and columns {128*h + 32*wc + 0..31}, h = 0,1, so each
+// half-tile is read in exactly one phase and can be restaged right after it:
+//     phase   LDS reads (this K tile)        MFMA quadrant      DMA issued
+//       1     W[0] sub (4) + A[0] sub (8)    (A0, W0)           A[1] of K tile t+1
+//       2     W[1] sub (4)                   (A0, W1)           W[0] of K tile t+2
+//       3     A[1] sub (8)                   (A1, W1)           A[0] of K tile t+2
+//       4     -                              (A1, W0)           W[1] of K tile t+2, then vmcnt(6): K tile t+1 landed
+// Needs N % 256 == 0 rows of W to exist (clamped like A otherwise) and an even K/64 >= 4.
+#define UV_SB() __builtin_amdgcn_s_barrier()
+#define UV_SCHED() __builtin_amdgcn_sched_barrier(0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
+    constexpr bool TRANS = (EPI == UV_EPI_BF16_T);
+    constexpr int HALF = 16384;      // one half-tile: 128 rows x 128 B
+    constexpr int BUF = 4 * HALF;    // A[0] A[1] W[0] W[1]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GM = 4;
+    const int group_sz = GM * p.tiles_n;
+    const int group = bid / group_sz;
+    const int first_m = group * GM;
+    const int gm = min(GM, p.tiles_m - first_m);
+    const int in_group = bid - group * group_sz;
+    const int m0 = (first_m + in_group % gm) * 256, n0 = (in_group / gm) * 256;
+
+    // staging sources: half-tile h, wave-instruction i covers rows (i*8 + wave)*8 + srow of the half-tile
+    const int srow = lane >> 3, pchunk = lane & 7;
+    const bf16_t* a_src[2][2];
+    const bf16_t* w_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 8 + wave) * 8 + srow;
+            const int c = pchunk ^ ((row >> 1) & 7);
+            a_src[h][i] = p.A + (long)min(m0 + h * 128 + row, p.M - 1) * p.lda + c * 8;
+            w_src[h][i] = p.W + (long)min(n0 + h * 128 + row, p.N - 1) * p.ldw + c * 8;
+        }
+    char* const my_dst = smem + wave * 1024;
+    const int nk = p.K / UV_BK;
+#define UV_STAGE(SRC, KT, DSTOFF)                                         \
+    {                                                                     \
+        const bf16_t* g0_ = SRC[0] + (long)(KT) * UV_BK;                  \
+        const bf16_t* g1_ = SRC[1] + (long)(KT) * UV_BK;                  \
+        glds16(g0_, (lds_void*)(my_dst + (DSTOFF)));                      \
+        glds16(g1_, (lds_void*)(my_dst + (DSTOFF) + 8192));              \
+    }
+
+    // fragment reads: row = 64*wr (A) / 32*wc (W) + 16*frag + frow, chunk (ks*4 + fq) ^ (frow >> 1)
+    const int frow = lane & 15, fq = lane >> 4;
+    const int lx = (fq ^ (frow >> 1)) << 4;
+    const char* const la = smem + (wr * 64 + frow) * 128;
+    const char* const lw = smem + 2 * HALF + (wc * 32 + frow) * 128;
+
+    f32x4 acc[2][2][2][4];  // [hn][hm][i][j]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], w0[2][2], w1[2][2];
+
+#define UV_RD_A(B, H)                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        af[j][0] = *(const bf16x8*)(la + (B) * BUF + (H) * HALF + j * 2048 + lx);                 \
+        af[j][1] = *(const bf16x8*)(la + (B) * BUF + (H) * HALF + j * 2048 + (lx ^ 64));          \
+    }
+#define UV_RD_W(B, H, WF)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
+        WF[i][0] = *(const bf16x8*)(lw + (B) * BUF + (H) * HALF + i * 2048 + lx);                 \
+        WF[i][1] = *(const bf16x8*)(lw + (B) * BUF + (H) * HALF + i * 2048 + (lx ^ 64));          \
+    }
+#define UV_MFMA_Q(HM, HN, WF)                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        if (TRANS)                                                                                \
+            acc[HN][HM][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][ks], WF[i][ks], acc[HN][HM][i][j], 0, 0, 0); \
+        else                                                                                      \
+            acc[HN][HM][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i][ks], af[j][ks], acc[HN][HM][i][j], 0, 0, 0); \
+    }                                                                                             \
+    __builtin_amdgcn_s_setprio(0);
+#define UV_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// one K tile T living in buffer B (the other buffer is O); ST1: K tile T+1 exists, ST2: K tile T+2 exists
+#define UV_KTILE(T, B, O, ST1, ST2)                                                               \
+    UV_RD_W(B, 0, w0) UV_SCHED(); UV_RD_A(B, 0)                                                   \
+    if (ST1) UV_STAGE(a_src[1], (T) + 1, (O) * BUF + HALF)                                        \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                            \
+    UV_SB(); UV_LGKM0(); UV_SCHED();                                                              \
+    UV_MFMA_Q(0, 0, w0) UV_SCHED(); UV_SB();                                                      \
+    UV_RD_W(B, 1, w1)                                                                             \
+    if (ST2) UV_STAGE(w_src[0], (T) + 2, (B) * BUF + 2 * HALF)                                    \
+    UV_SB(); UV_LGKM0(); UV_SCHED();                                                              \
+    UV_MFMA_Q(0, 1, w1) UV_SCHED(); UV_SB();                                                      \
+    UV_RD_A(B, 1)                                                                                 \
+    if (ST2) UV_STAGE(a_src[0], (T) + 2, (B) * BUF)                                               \
+    UV_SB(); UV_LGKM0(); UV_SCHED();                                                              \
+    UV_MFMA_Q(1, 1, w1) UV_SCHED(); UV_SB();                                                      \
+    if (ST2) {                                                                                    \
+        UV_STAGE(w_src[1], (T) + 2, (B) * BUF + 3 * HALF)                                         \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                          \
+    } else {                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+    }                                                                                             \
+    UV_SB(); UV_SCHED();                                                                          \
+    UV_MFMA_Q(1, 0, w0) UV_SCHED(); UV_SB();
+
+    // prologue: K tile 0 (W0 A0 W1 A1) and W0 A0 W1 of K tile 1; vmcnt(6) = K tile 0 landed
+    UV_STAGE(w_src[0], 0, 2 * HALF) UV_STAGE(a_src[0], 0, 0) UV_STAGE(w_src[1], 0, 3 * HALF) UV_STAGE(a_src[1], 0, HALF)
+    UV_STAGE(w_src[0], 1, BUF + 2 * HALF) UV_STAGE(a_src[0], 1, BUF) UV_STAGE(w_src[1], 1, BUF + 3 * HALF)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    UV_SB();
+    if (wr == 1) UV_SB();  // the second group runs one barrier behind the first
+
+    int t = 0;
+    for (; t + 2 < nk; t += 2) {
+        UV_KTILE(t, 0, 1, true, true)
+        UV_KTILE(t + 1, 1, 0, true, true)
+    }
+    UV_KTILE(t, 0, 1, true, false)
+    UV_KTILE(t + 1, 1, 0, false, false)
+    if (wr == 0) UV_SB();
+
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    epi_frag<EPI>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], frow, fq);
+}
+
+static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
+    GemmArgs a = a0;
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 255) / 256;
+    const dim3 grid(a.tiles_m * a.tiles_n), block(512);
+    const size_t lds = 128 * 1024;
+#define UV_LAUNCH8(E)                                                                              \
+    case E: {                                                                                      \
+        auto kern = gemm_bf16_8ph_kernel<E>;                                                       \
+        static bool attr_set = false;                                                              \
+        if (!attr_set) {                                                                           \
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                (int)lds);                                                         \
+            attr_set = true;                                                                       \
+        }                                                                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                     \
+        break;                                                                                     \
+    }
+    switch (epi) {
+        UV_LAUNCH8(UV_EPI_BF16)
+        UV_LAUNCH8(UV_EPI_GELU_BF16)
+        UV_LAUNCH8(UV_EPI_F32_FROM_BF16)
+        UV_LAUNCH8(UV_EPI_RESID_F32)
+        UV_LAUNCH8(UV_EPI_GATE_RESID_F32)
+        UV_LAUNCH8(UV_EPI_BF16_T)
+        default:
+            uv_set_error("uv_gemm_bf16_nt: unknown epilogue %d", epi);
+            return -1;
+    }
+#undef UV_LAUNCH8
+    UV_CHECK_LAUNCH("uv_gemm_bf16_nt");
+    return 0;
+}
+
+template <int BM, int BN, int WM, int WN, int NS = 2>
 static int launch_cfg(const GemmArgs& a0, int epi, hipStream_t stream) {
     GemmArgs a = a0;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     const dim3 grid(a.tiles_m * a.tiles_n), block(WM * WN * 64);
-    const size_t lds = 2 * (BM + BN) * 128;
+    const size_t lds = NS * (BM + BN) * 128;
 #define UV_LAUNCH(E)                                                                               \
     case E: {                                                                                      \
-        auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, E>;                                        \
+        auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, E, NS>;                                     \
         static bool attr_set = false;                                                              \
         if (!attr_set) {                                                                           \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
@@ -285,6 +491,37 @@ static int launch_cfg(const GemmArgs& a0, int epi, hipStream_t stream) {
     return 0;
 }
 
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStream_t s);
+
+// Rows that fill whole rounds of 256x256 tiles go to the big-tile kernel; the leftover rows (which would otherwise cost a
+// whole extra round on a fraction of the CUs) run as 128x128 tiles. Same arithmetic per element either way.
+static int launch_m_split(const GemmArgs& a, int epilogue, int main_cfg, hipStream_t s) {
+    const long tiles_n = (a.N + 255) / 256, tiles_m = (a.M + 255) / 256;
+    const long rounds = tiles_m * tiles_n / num_cus();
+    const long m_main = rounds * num_cus() / tiles_n * 256;
+    if (rounds == 0 || m_main <= 0 || m_main >= a.M) return launch_by_cfg(a, epilogue, main_cfg, s);
+    GemmArgs am = a, at = a;
+    am.M = (int)m_main;
+    at.M = a.M - (int)m_main;
+    at.A = a.A + m_main * a.lda;
+    if (a.gate_tid) at.gate_tid = a.gate_tid + m_main;
+    if (epilogue == UV_EPI_BF16_T) at.out = (bf16_t*)a.out + m_main;
+    else if (epilogue == UV_EPI_BF16 || epilogue == UV_EPI_GELU_BF16) at.out = (bf16_t*)a.out + m_main * a.ldo;
+    else at.out = (float*)a.out + m_main * a.ldo;
+    const int rc = launch_by_cfg(am, epilogue, main_cfg, s);
+    return rc ? rc : launch_by_cfg(at, epilogue, 10, s);
+}
+
 extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw, const void* bias_bf16,
                                int M, int N, int K, int epilogue, void* out, long ldo,
                                const float* gate, const int32_t* gate_tid, long gate_stride,
@@ -305,16 +542,32 @@ extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw,
     a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.gate_stride = gate_stride;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
+    if (tile_cfg == 0 && M >= 2048 && N >= 1024 && N % 256 == 0 && K % 128 == 0 && K >= 256) {
+        // Large projections: 256x256 tiles, one workgroup per CU. The 8-wave ping-pong kernel is the faster main loop
+        // (clearly so for long K and for the transposed epilogue); the fp32 read-modify-write epilogues run a little
+        // better from the 16-wave kernel at short K. When the tile count is just above a whole number of rounds, the
+        // leftover rows are split off so they do not cost a full extra round.
+        const bool rmw = epilogue == UV_EPI_GATE_RESID_F32 || epilogue == UV_EPI_RESID_F32;
+        const int main_cfg = (rmw && K <= 4096) ? 5 : 7;
+        const long tiles = (long)((M + 255) / 256) * (N / 256);
+        const long rounds = tiles / num_cus(), rest = tiles - rounds * num_cus();
+        if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) return launch_m_split(a, epilogue, main_cfg, s);
+        return launch_by_cfg(a, epilogue, main_cfg, s);
+    }
+    if (tile_cfg == 8) return launch_m_split(a, epilogue, 7, s);
+    if (tile_cfg == 9) return launch_m_split(a, epilogue, 5, s);
+    return launch_by_cfg(a, epilogue, tile_cfg, s);
+}
+
+static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStream_t s) {
+    const int M = a.M, N = a.N, K = a.K;
     switch (tile_cfg) {
-        case 0: {  // default: the big tile whose grid quantises best onto the 256 CUs (1 block per CU)
+        case 0: {  // default (only reached for shapes the split/ping-pong path in uv_gemm_bf16_nt does not take)
             if (M < 2048 || N < 1024) return launch_cfg<128, 128, 2, 2>(a, epilogue, s);
             const long tm = (M + 255) / 256;
             const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
             // cost ~ rounds x tile area; 256x192 tiles carry 3/4 of the work of 256x256 at slightly lower efficiency
             const double c256 = (double)((t256 + 255) / 256) * 1.00, c192 = (double)((t192 + 255) / 256) * 0.78;
-            // 16 waves per workgroup (64x64 / 64x48 per wave, 4 waves per SIMD): more waves to hide the LDS and DMA
-            // latency than the 8-wave layout (measured +6 % on the ffn.0 shape)
-            // long-K shapes (ffn.2, K = 14336) stream A once per n-tile: the wider tile wins there despite worse quantisation
             if (N % 192 == 0 && c192 < c256 && K <= 4096) return launch_cfg<256, 192, 4, 4>(a, epilogue, s);
             return launch_cfg<256, 256, 4, 4>(a, epilogue, s);
         }
@@ -324,6 +577,10 @@ extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw,
         case 4: return launch_cfg<256, 192, 2, 4>(a, epilogue, s);
         case 5: return launch_cfg<256, 256, 4, 4>(a, epilogue, s);
         case 6: return launch_cfg<256, 192, 4, 4>(a, epilogue, s);
+        case 10: return launch_cfg<128, 128, 2, 2, 4>(a, epilogue, s);
+        case 7:
+            UV_CHECK_ARG(K % 128 == 0 && K >= 256, "uv_gemm_bf16_nt: tile_cfg 7 needs K %% 128 == 0 and K >= 256 (K=%d)", K);
+            return launch_8ph(a, epilogue, s);
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown tile_cfg %d", tile_cfg);
             return -1;
