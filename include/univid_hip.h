@@ -54,8 +54,9 @@ int uv_gemm_f32_nt(const float* A, long lda, const float* W, long ldw, const flo
 /* out[Lq, H*D] = softmax(q k^T * softmax_scale) v per head, non-causal, all Lk keys attended, for `batch` independent
  * samples. Replaces flash_attention() (attention.py:24-130) as called at model.py:145-150 and :175.
  * q [batch*Lq, ldq], k [batch*Lk, ldk] bf16 (samples stacked along the token axis) with head h at columns
- * [h*D, (h+1)*D); vt = V TRANSPOSED, bf16 [batch*H*D, ldvt] (samples stacked along the channel-row axis) with
- * ldvt >= roundup(Lk, 64) and finite padding; out [batch*Lq, ldo]; head_dim D in {64, 128}. */
+ * [h*D, (h+1)*D); vt = V TRANSPOSED, bf16 [H*D, ldvt]: sample b's keys are columns [b*Lk, (b+1)*Lk) (so one
+ * UV_EPI_BF16_T GEMM over the stacked rows produces it), ldvt >= (batch-1)*Lk + roundup(Lk, 64), every column up to
+ * that bound finite, Lk % 8 == 0 when batch > 1; out [batch*Lq, ldo]; head_dim D in {64, 128}. */
 int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                        int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream);
 

@@ -372,6 +372,31 @@ def test_attention_modules_reference_signatures():
         assert d.abs().max() <= 2e-2 * ref.float().abs().max(), cls.__name__
 
 
+def test_flash_attention_stacked_samples_match_single_calls():
+    """batch > 1: q/k/out rows and V^T COLUMNS are stacked per sample (what one UV_EPI_BF16_T GEMM over the stacked rows
+    writes); every sample's result is bit-identical to its own batch-1 call, ragged last key tile included."""
+    from univid_amd._lib import EPI_BF16_T
+    H, D, Lq, Lk, B = 2, 128, 200, 136, 3
+    C = H * D
+    g = torch.Generator(device=DEV).manual_seed(9)
+    q = torch.randn(B * Lq, C, generator=g, device=DEV).to(BF16)
+    k = torch.randn(B * Lk, C, generator=g, device=DEV).to(BF16)
+    v = torch.randn(B * Lk, C, generator=g, device=DEV).to(BF16)
+    eye = torch.eye(C, device=DEV).to(BF16)
+    cols = (B - 1) * Lk + (Lk + 63) // 64 * 64
+    vt = torch.zeros(C, cols, dtype=BF16, device=DEV)
+    L().gemm_bf16(v, eye, None, vt, EPI_BF16_T)                      # V^T of the stacked rows in one launch
+    assert torch.equal(vt[:, :B * Lk], v.t())
+    out = torch.zeros(B * Lq, C, dtype=BF16, device=DEV)
+    L().flash_attn(q, k, vt, out, Lq, Lk, H, D, D ** -0.5, batch=B)
+    for b in range(B):
+        vt1 = torch.zeros(C, (Lk + 63) // 64 * 64, dtype=BF16, device=DEV)
+        vt1[:, :Lk] = v[b * Lk:(b + 1) * Lk].t()
+        o1 = torch.zeros(Lq, C, dtype=BF16, device=DEV)
+        L().flash_attn(q[b * Lq:(b + 1) * Lq], k[b * Lk:(b + 1) * Lk], vt1, o1, Lq, Lk, H, D, D ** -0.5)
+        assert torch.equal(out[b * Lq:(b + 1) * Lq], o1), f"sample {b}"
+
+
 def test_dit_batched_forward_is_bit_identical_to_sequential():
     """Samples of equal shape run as one stacked pass (the CFG cond/uncond pair in WanTI2V.denoise): per-sample results
     must not change by a single bit; mixed shapes fall back to one-by-one."""

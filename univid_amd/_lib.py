@@ -164,7 +164,7 @@ def gemm_f32(a, w, bias, out, resid=None, M=None):
 
 
 def flash_attn(q, k, vt, out, Lq, Lk, H, D, scale, batch=1):
-    """q [batch*Lq, C], k [batch*Lk, C], vt [batch*C, >= roundup(Lk, 64)], out [batch*Lq, C]; C = H*D."""
+    """q [batch*Lq, C], k [batch*Lk, C], vt [C, >= (batch-1)*Lk + roundup(Lk, 64)] (sample b = columns b*Lk..), out [batch*Lq, C]."""
     for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (out, "out")):
         _chk(t, torch.bfloat16, "flash_attn." + n)
     call("uv_flash_attn_bf16", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(vt), vt.stride(0), ptr(out), out.stride(0),

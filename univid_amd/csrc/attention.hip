@@ -68,11 +68,11 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
     const int bh = blockIdx.x / p.q_blocks;
     const int qb = blockIdx.x - bh * p.q_blocks;
     const int head = bh % p.H;
-    {   // independent samples are stacked along the token axis (q/k/out) resp. along the channel-row axis (V^T)
+    {   // independent samples are stacked along the token axis: rows of q/k/out, COLUMNS of V^T
         const long b = bh / p.H;
         p.q += b * p.Lq * p.ldq;
         p.k += b * p.Lk * p.ldk;
-        p.vt += b * p.H * D * p.ldvt;
+        p.vt += (long)b * p.Lk;
         p.out += b * p.Lq * p.ldo;
     }
     const int q0w = qb * (NW * UV_ATT_QW) + wave * UV_ATT_QW;
@@ -297,8 +297,9 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
     UV_CHECK_ARG(Lq > 0 && Lk > 0 && H > 0 && batch > 0, "uv_flash_attn_bf16: bad shape B=%d Lq=%d Lk=%d H=%d", batch, Lq, Lk, H);
     UV_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0,
                  "uv_flash_attn_bf16: leading dimensions must be multiples of 8 elements");
-    UV_CHECK_ARG(ldvt >= (long)((Lk + 63) / 64) * 64,
-                 "uv_flash_attn_bf16: ldvt=%ld must cover Lk=%d rounded up to 64", ldvt, Lk);
+    UV_CHECK_ARG(ldvt >= (long)(batch - 1) * Lk + (long)((Lk + 63) / 64) * 64,
+                 "uv_flash_attn_bf16: ldvt=%ld must cover (batch-1)*Lk + Lk rounded up to 64 (batch=%d Lk=%d)", ldvt, batch, Lk);
+    UV_CHECK_ARG(batch == 1 || Lk % 8 == 0, "uv_flash_attn_bf16: batch > 1 needs Lk %% 8 == 0 (Lk=%d)", Lk);
     UV_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0,
                  "uv_flash_attn_bf16: pointers must be 16-byte aligned");
     AttnArgs a;

@@ -519,7 +519,7 @@ static int launch_m_split(const GemmArgs& a, int epilogue, int main_cfg, hipStre
     else if (epilogue == UV_EPI_BF16 || epilogue == UV_EPI_GELU_BF16) at.out = (bf16_t*)a.out + m_main * a.ldo;
     else at.out = (float*)a.out + m_main * a.ldo;
     const int rc = launch_by_cfg(am, epilogue, main_cfg, s);
-    return rc ? rc : launch_by_cfg(at, epilogue, 10, s);
+    return rc ? rc : launch_by_cfg(at, epilogue, 12, s);
 }
 
 extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw, const void* bias_bf16,
@@ -563,7 +563,13 @@ static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStrea
     const int M = a.M, N = a.N, K = a.K;
     switch (tile_cfg) {
         case 0: {  // default (only reached for shapes the split/ping-pong path in uv_gemm_bf16_nt does not take)
-            if (M < 2048 || N < 1024) return launch_cfg<128, 128, 2, 2>(a, epilogue, s);
+            if (M < 2048 || N < 1024) {
+                // few tiles (at most ~2 per CU): 8 waves on a 4-stage ring hide the DMA/LDS latency that one 4-wave
+                // workgroup per CU leaves exposed; many tiles: 4-wave workgroups, 2-3 resident per CU
+                const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+                if (t128 <= 2 * num_cus()) return launch_cfg<128, 128, 4, 2, 4>(a, epilogue, s);
+                return launch_cfg<128, 128, 2, 2>(a, epilogue, s);
+            }
             const long tm = (M + 255) / 256;
             const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
             // cost ~ rounds x tile area; 256x192 tiles carry 3/4 of the work of 256x256 at slightly lower efficiency
@@ -578,6 +584,9 @@ static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStrea
         case 5: return launch_cfg<256, 256, 4, 4>(a, epilogue, s);
         case 6: return launch_cfg<256, 192, 4, 4>(a, epilogue, s);
         case 10: return launch_cfg<128, 128, 2, 2, 4>(a, epilogue, s);
+        case 11: return launch_cfg<128, 128, 2, 4, 4>(a, epilogue, s);
+        case 12: return launch_cfg<128, 128, 4, 2, 4>(a, epilogue, s);
+        case 13: return launch_cfg<128, 128, 2, 4, 2>(a, epilogue, s);
         case 7:
             UV_CHECK_ARG(K % 128 == 0 && K >= 256, "uv_gemm_bf16_nt: tile_cfg 7 needs K %% 128 == 0 and K >= 256 (K=%d)", K);
             return launch_8ph(a, epilogue, s);

@@ -96,13 +96,12 @@ class WanSelfAttention(nn.Module):
         M = batch * L
         ql = torch.empty(M, C, dtype=BF16, device=dev)
         kl = torch.empty(M, C, dtype=BF16, device=dev)
-        Lp = _round_up(L, 64)
-        vt = _zeros_cached(("vt", batch * C, Lp, dev), (batch * C, Lp), BF16, dev)
+        vt = _vt_scratch("vt", C, batch, L, dev)
         _lib.gemm_bf16(h, p["q"].w, p["q"].b, ql, EPI_BF16, M=M)
         _lib.gemm_bf16(h, p["k"].w, p["k"].b, kl, EPI_BF16, M=M)
-        for b in range(batch):   # V^T and RoPE are per sample (transposed output / token position)
+        _lib.gemm_bf16(h, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=M)   # V^T [C, tokens]: sample b = columns b*L..
+        for b in range(batch):   # RoPE positions restart with every sample
             rows = slice(b * L, (b + 1) * L)
-            _lib.gemm_bf16(h[rows], p["v"].w, p["v"].b, vt[b * C:(b + 1) * C], EPI_BF16_T, M=L)
             _lib.rmsnorm_rope(ql[rows], ql[rows], self.norm_q.weight, L, C, D, self.eps, freqs, grid)
             _lib.rmsnorm_rope(kl[rows], kl[rows], self.norm_k.weight, L, C, D, self.eps, freqs, grid)
         att = torch.empty(M, C, dtype=BF16, device=dev)
@@ -150,12 +149,10 @@ class WanCrossAttention(WanSelfAttention):
         dev = hq.device
         ql = torch.empty(batch * L, C, dtype=BF16, device=dev)
         kl = torch.empty(batch * Lc, C, dtype=BF16, device=dev)
-        Lcp = _round_up(Lc, 64)
-        vt = _zeros_cached(("cvt", batch * C, Lcp, dev), (batch * C, Lcp), BF16, dev)
+        vt = _vt_scratch("cvt", C, batch, Lc, dev)
         _lib.gemm_bf16(hq, p["q"].w, p["q"].b, ql, EPI_BF16, M=batch * L)
         _lib.gemm_bf16(ctx, p["k"].w, p["k"].b, kl, EPI_BF16, M=batch * Lc)
-        for b in range(batch):
-            _lib.gemm_bf16(ctx[b * Lc:(b + 1) * Lc], p["v"].w, p["v"].b, vt[b * C:(b + 1) * C], EPI_BF16_T, M=Lc)
+        _lib.gemm_bf16(ctx, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=batch * Lc)
         _lib.rmsnorm_rope(ql, ql, self.norm_q.weight, batch * L, C, D, self.eps)
         _lib.rmsnorm_rope(kl, kl, self.norm_k.weight, batch * Lc, C, D, self.eps)
         att = torch.empty(batch * L, C, dtype=BF16, device=dev)
@@ -289,6 +286,14 @@ def _zeros_cached(key, shape, dtype, device):
         t = torch.zeros(shape, dtype=dtype, device=device)
         _zero_cache[key] = t
     return t
+
+
+def _vt_scratch(tag, C, batch, L, device):
+    """V^T [C, columns]: sample b's keys are columns [b*L, (b+1)*L); the tail up to the 64-key tile bound stays zero."""
+    if batch > 1 and L % 8:
+        raise NotImplementedError(f"stacked samples need a token count divisible by 8 (got {L}); run them one by one")
+    cols = (batch - 1) * L + _round_up(L, 64)
+    return _zeros_cached((tag, C, cols, device), (C, cols), BF16, device)
 
 
 def _ensure_prepared(mod):
@@ -440,7 +445,11 @@ class WanModel(nn.Module):
         # so each sample's result is bit-identical to running it alone; the benefit is occupancy (e.g. CFG's cond + uncond
         # pair: 4320 attention workgroups instead of 2 x 2160 on 512 slots) and weight reuse. Mixed shapes run one by one.
         xs_in = [u.to(device=dev, dtype=torch.float32).contiguous() for u in x]
-        groups = [list(range(len(xs_in)))] if len({tuple(u.shape) for u in xs_in}) == 1 else [[i] for i in range(len(xs_in))]
+        same = len({tuple(u.shape) for u in xs_in}) == 1
+        if same:   # stacking needs 16-byte aligned per-sample columns in V^T: token count and context length % 8 == 0
+            _, F0, H0, W0 = xs_in[0].shape
+            same = ((F0 // pt) * (H0 // ph) * (W0 // pw)) % 8 == 0 and self.text_len % 8 == 0
+        groups = [list(range(len(xs_in)))] if same else [[i] for i in range(len(xs_in))]
         outs = [None] * len(xs_in)
         for idx in groups:
             B = len(idx)
