@@ -145,9 +145,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
-    from oracle.wan_dit import TI2V_5B_CFG  # constants only (configs/wan_ti2v_5B.py:17-29)
+    from univid_amd.wan.textimage2video import TI2VConfig   # configs/wan_ti2v_5B.py:17-29
     from univid_amd import _lib
     from univid_amd.wan.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    TI2V_5B_CFG = {k: v for k, v in TI2VConfig.dit.items() if k not in ("model_type", "window_size", "qk_norm", "cross_attn_norm")}
     cfg = dict(TI2V_5B_CFG)
     if args.layers:
         cfg["num_layers"] = args.layers

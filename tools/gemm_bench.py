@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from univid_amd import _lib  # noqa: E402
-from univid_amd._lib import EPI_BF16, EPI_GELU_BF16, EPI_GATE_RESID_F32, EPI_BF16_T  # noqa: E402
+from univid_amd._lib import EPI_BF16, EPI_GELU_BF16, EPI_GATE_RESID_F32, EPI_BF16_T, EPI_F32_FROM_BF16, EPI_RESID_F32  # noqa: E402
 
 L2 = 22880  # cond+uncond stacked tokens at 704x1280x49 (2 x 11440)
 SHAPES = [
@@ -27,6 +27,8 @@ SHAPES = [
     ("ffn.0 without gelu", L2, 14336, 3072, EPI_BF16),
     ("tail strip K=3072", 1120, 3072, 3072, EPI_BF16),
     ("tail strip K=14336", 1120, 3072, 14336, EPI_GATE_RESID_F32),
+    ("o-shape, f32 write only", L2, 3072, 3072, EPI_F32_FROM_BF16),
+    ("o-shape, f32 resid", L2, 3072, 3072, EPI_RESID_F32),
 ]
 
 
@@ -49,7 +51,9 @@ def main():
         W = ((torch.rand(N, K, device=dev, generator=g) * 2 - 1) * 0.05).to(torch.bfloat16)
         bias = (torch.rand(N, device=dev, generator=g) - 0.5).to(torch.bfloat16)
         gate = gate_tid = None
-        if epi == EPI_GATE_RESID_F32:
+        if epi in (EPI_F32_FROM_BF16, EPI_RESID_F32):
+            out = torch.rand(M, N, device=dev, generator=g)
+        elif epi == EPI_GATE_RESID_F32:
             out = torch.rand(M, N, device=dev, generator=g)
             gate = torch.rand(2, N, device=dev, generator=g)
             gate_tid = (torch.arange(M, device=dev) * 2 // M).to(torch.int32)

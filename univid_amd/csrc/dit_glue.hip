@@ -28,71 +28,99 @@ struct LnArgs {
     int mode, round_ln, out_bf16;
 };
 
-template <int MAXV>
+// A 4-wave block walks 4*RPW consecutive token rows, one row per wave at a time. The modulation (or affine) parameters of
+// the block's first row are staged in LDS once and read from there by every row with the same table index (the usual
+// case: a sample's tokens share one timestep); the parameter reads are otherwise 2x the x reads in load instructions.
+template <int MAXV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(LnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char ln_smem[];
+    f32x4* sp = (f32x4*)ln_smem;                 // [2][nv*64]: scale|shift (mode 1) or w|b (mode 2)
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.L) return;
-    const int nv = p.C >> 8;  // float4 per lane
-    const float* xr = p.x + (long)row * p.ldx;
-    f32x4 v[MAXV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (i < nv) {
-            v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const int wave = threadIdx.x >> 6;
+    const int nv = p.C >> 8;                      // float4 per lane
+    const int brow0 = blockIdx.x * 4 * RPW;
+    int t_blk = 0;
+    if (p.mode != 0) {
+        const float *a0, *b0;
+        if (p.mode == 1) {
+            t_blk = p.tid ? p.tid[brow0] : 0;
+            a0 = p.tab + (long)t_blk * p.tab_stride + p.scale_off;
+            b0 = p.tab + (long)t_blk * p.tab_stride + p.shift_off;
+        } else {
+            a0 = p.w;
+            b0 = p.b;
         }
-    const float mean = wave_sum(s) / (float)p.C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (i < nv) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[i][e] - mean;
-                q += d * d;
-            }
+        for (int i = threadIdx.x; i < nv * 64; i += 256) {
+            sp[i] = *(const f32x4*)(a0 + i * 4);
+            sp[nv * 64 + i] = *(const f32x4*)(b0 + i * 4);
         }
-    const float var = wave_sum(q) / (float)p.C;
-    const float rstd = 1.0f / sqrtf(var + p.eps);
-
-    const float* shift = nullptr;
-    const float* scale = nullptr;
-    if (p.mode == 1) {
-        const int t = p.tid ? p.tid[row] : 0;
-        shift = p.tab + (long)t * p.tab_stride + p.shift_off;
-        scale = p.tab + (long)t * p.tab_stride + p.scale_off;
+        __syncthreads();
     }
+    for (int r = 0; r < RPW; ++r) {
+        const int row = brow0 + r * 4 + wave;
+        if (row >= p.L) break;
+        const float* xr = p.x + (long)row * p.ldx;
+        f32x4 v[MAXV];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (i < nv) {
-            const int c = (i * 64 + lane) * 4;
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = __fmul_rn(v[i][e] - mean, rstd);
-                if (p.round_ln) t = round_bf(t);
-                y[e] = t;
+        for (int i = 0; i < MAXV; ++i)
+            if (i < nv) {
+                v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
+                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
-            if (p.mode == 1) {
-                const f32x4 sc = *(const f32x4*)(scale + c);
-                const f32x4 sh = *(const f32x4*)(shift + c);
+        const int t = (p.mode == 1 && p.tid) ? __builtin_amdgcn_readfirstlane(p.tid[row]) : 0;
+        const bool from_lds = p.mode == 2 || t == t_blk;
+        const float* scale = p.tab + (long)t * p.tab_stride + p.scale_off;   // used only when the row's index differs
+        const float* shift = p.tab + (long)t * p.tab_stride + p.shift_off;
+        const float mean = wave_sum(s) / (float)p.C;
+        float q = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], __fadd_rn(1.0f, sc[e])), sh[e]);
-            } else if (p.mode == 2) {
-                const f32x4 w = *(const f32x4*)(p.w + c);
-                const f32x4 b = *(const f32x4*)(p.b + c);
+        for (int i = 0; i < MAXV; ++i)
+            if (i < nv) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], w[e]), b[e]);
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[i][e] - mean;
+                    q += d * d;
+                }
             }
-            if (p.out_bf16) {
-                u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-                *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;
-            } else {
-                *(f32x4*)((float*)p.out + (long)row * p.ldo + c) = y;
+        const float var = wave_sum(q) / (float)p.C;
+        const float rstd = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (i < nv) {
+                const int c = (i * 64 + lane) * 4;
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float tt = __fmul_rn(v[i][e] - mean, rstd);
+                    if (p.round_ln) tt = round_bf(tt);
+                    y[e] = tt;
+                }
+                if (p.mode != 0) {
+                    f32x4 pa, pb;
+                    if (from_lds) {
+                        pa = sp[i * 64 + lane];
+                        pb = sp[nv * 64 + i * 64 + lane];
+                    } else {
+                        pa = *(const f32x4*)(scale + c);
+                        pb = *(const f32x4*)(shift + c);
+                    }
+                    if (p.mode == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], __fadd_rn(1.0f, pa[e])), pb[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], pa[e]), pb[e]);
+                    }
+                }
+                if (p.out_bf16) {
+                    u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+                    *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;
+                } else {
+                    *(f32x4*)((float*)p.out + (long)row * p.ldo + c) = y;
+                }
             }
-        }
+    }
 }
 
 extern "C" int uv_layernorm_mod(const float* x, long ldx, void* out, long ldo, int L, int C, float eps,
@@ -107,10 +135,15 @@ extern "C" int uv_layernorm_mod(const float* x, long ldx, void* out, long ldo, i
                                 "uv_layernorm_mod: modulation table missing / misaligned");
     if (mode == 2) UV_CHECK_ARG(w && b, "uv_layernorm_mod: affine weight/bias missing");
     LnArgs a{x, ldx, out, ldo, tab, tab_stride, shift_off, scale_off, tid, w, b, L, C, eps, mode, round_ln, out_bf16};
+    // one row per wave: measured 4.2-4.4 TB/s; 2 or 4 rows per wave run the waves of a CU in lockstep (all loading, then
+    // all storing) and lose 15-30 %, so the LDS staging only trims the parameter reads to one copy per 4 rows
     const dim3 grid((L + 3) / 4), block(256);
-    if (C <= 1024) hipLaunchKernelGGL(layernorm_mod_kernel<4>, grid, block, 0, (hipStream_t)stream, a);
-    else if (C <= 4096) hipLaunchKernelGGL(layernorm_mod_kernel<16>, grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(layernorm_mod_kernel<32>, grid, block, 0, (hipStream_t)stream, a);
+    const size_t lds = mode == 0 ? 0 : (size_t)2 * (C / 4) * 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 1024) hipLaunchKernelGGL((layernorm_mod_kernel<4, 1>), grid, block, lds, st, a);
+    else if (C <= 3072) hipLaunchKernelGGL((layernorm_mod_kernel<12, 1>), grid, block, lds, st, a);
+    else if (C <= 4096) hipLaunchKernelGGL((layernorm_mod_kernel<16, 1>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((layernorm_mod_kernel<32, 1>), grid, block, lds, st, a);
     UV_CHECK_LAUNCH("uv_layernorm_mod");
     return 0;
 }
@@ -136,67 +169,100 @@ struct RmsRopeArgs {
     float eps;
 };
 
-template <int MAXV>
+// One wave walks RPW consecutive token rows; the norm weight of its columns stays in registers. A lane's 8-element
+// chunks sit 512 columns apart, so when head_dim divides 512 they all map to the same 4 complex RoPE columns of a head:
+// the factors are fetched once per row instead of once per chunk.
+template <int MAXV, int RPW>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsRopeArgs p) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.L) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= p.L) return;
     const int nv = p.C >> 9;                     // 8-element chunks per lane (64 lanes * 8 = 512)
     const int rem = (p.C & 511) >> 3;            // leftover chunks (C % 512 != 0, e.g. C = 256)
-    const bf16_t* xr = p.x + (long)row * p.ldx;
-    float v[MAXV][8];
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const bool on = (i < nv) || (i == nv && lane < rem);
-        if (on) {
-            const u32x4 raw = *(const u32x4*)(xr + (i * 64 + lane) * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[i][2 * e] = bf2f((bf16_t)(raw[e] & 0xffff));
-                v[i][2 * e + 1] = bf2f((bf16_t)(raw[e] >> 16));
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
-        }
-    }
-    const float mean = wave_sum(ss) / (float)p.C;
-    const float rs = 1.0f / sqrtf(mean + p.eps);
-
-    const bool do_rope = p.freqs != nullptr && row < p.F * p.Hh * p.Ww;
-    int pf = 0, ph = 0, pw = 0;
-    if (do_rope) {
-        pw = row % p.Ww;
-        const int t = row / p.Ww;
-        ph = t % p.Hh;
-        pf = t / p.Hh;
-    }
     const int half = p.D >> 1;
+    const bool same_cols = (512 % p.D) == 0;
+    f32x4 wv[MAXV][2];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const bool on = (i < nv) || (i == nv && lane < rem);
-        if (on) {
-            const int c0 = (i * 64 + lane) * 8;
-            float y[8];
+    for (int i = 0; i < MAXV; ++i)
+        if ((i < nv) || (i == nv && lane < rem)) {
+            wv[i][0] = *(const f32x4*)(p.weight + (i * 64 + lane) * 8);
+            wv[i][1] = *(const f32x4*)(p.weight + (i * 64 + lane) * 8 + 4);
+        }
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int row = row0 + rr;
+        if (row >= p.L) break;
+        const bf16_t* xr = p.x + (long)row * p.ldx;
+        float v[MAXV][8];
+        float ss = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(round_bf(__fmul_rn(v[i][e], rs)), p.weight[c0 + e]);
-            if (do_rope) {
-                const int pair0 = (c0 % p.D) >> 1;  // first complex index of this chunk inside its head
+        for (int i = 0; i < MAXV; ++i) {
+            const bool on = (i < nv) || (i == nv && lane < rem);
+            if (on) {
+                const u32x4 raw = *(const u32x4*)(xr + (i * 64 + lane) * 8);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int ci = pair0 + e;
-                    const int pos = ci < p.nf ? pf : (ci < p.nf + p.nh ? ph : pw);
-                    const double* fr = p.freqs + ((long)pos * half + ci) * 2;
-                    const double cr = fr[0], ci_ = fr[1];
-                    const double a = (double)y[2 * e], b = (double)y[2 * e + 1];
-                    const double re = __dsub_rn(__dmul_rn(a, cr), __dmul_rn(b, ci_));
-                    const double im = __dadd_rn(__dmul_rn(a, ci_), __dmul_rn(b, cr));
-                    y[2 * e] = (float)re;
-                    y[2 * e + 1] = (float)im;
+                    v[i][2 * e] = bf2f((bf16_t)(raw[e] & 0xffff));
+                    v[i][2 * e + 1] = bf2f((bf16_t)(raw[e] >> 16));
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
             }
-            u32x4 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]), pack_bf2(y[4], y[5]), pack_bf2(y[6], y[7])};
-            *(u32x4*)(p.out + (long)row * p.ldo + c0) = o;
+        }
+        const bool do_rope = p.freqs != nullptr && row < p.F * p.Hh * p.Ww;
+        int pf = 0, ph = 0, pw = 0;
+        if (do_rope) {
+            pw = row % p.Ww;
+            const int t = row / p.Ww;
+            ph = t % p.Hh;
+            pf = t / p.Hh;
+        }
+        double fcr[4], fci[4];   // this lane's 4 complex factors (valid for every chunk when same_cols)
+        if (do_rope && same_cols) {
+            const int pair0 = ((lane * 8) % p.D) >> 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = pair0 + e;
+                const int pos = ci < p.nf ? pf : (ci < p.nf + p.nh ? ph : pw);
+                const double* fr = p.freqs + ((long)pos * half + ci) * 2;
+                fcr[e] = fr[0];
+                fci[e] = fr[1];
+            }
+        }
+        const float mean = wave_sum(ss) / (float)p.C;
+        const float rs = 1.0f / sqrtf(mean + p.eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const bool on = (i < nv) || (i == nv && lane < rem);
+            if (on) {
+                const int c0 = (i * 64 + lane) * 8;
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(round_bf(__fmul_rn(v[i][e], rs)), wv[i][e >> 2][e & 3]);
+                if (do_rope) {
+                    const int pair0 = (c0 % p.D) >> 1;  // first complex index of this chunk inside its head
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        double cr, ci_;
+                        if (same_cols) {
+                            cr = fcr[e];
+                            ci_ = fci[e];
+                        } else {
+                            const int ci = pair0 + e;
+                            const int pos = ci < p.nf ? pf : (ci < p.nf + p.nh ? ph : pw);
+                            const double* fr = p.freqs + ((long)pos * half + ci) * 2;
+                            cr = fr[0];
+                            ci_ = fr[1];
+                        }
+                        const double a = (double)y[2 * e], b = (double)y[2 * e + 1];
+                        const double re = __dsub_rn(__dmul_rn(a, cr), __dmul_rn(b, ci_));
+                        const double im = __dadd_rn(__dmul_rn(a, ci_), __dmul_rn(b, cr));
+                        y[2 * e] = (float)re;
+                        y[2 * e + 1] = (float)im;
+                    }
+                }
+                u32x4 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]), pack_bf2(y[4], y[5]), pack_bf2(y[6], y[7])};
+                *(u32x4*)(p.out + (long)row * p.ldo + c0) = o;
+            }
         }
     }
 }
@@ -215,11 +281,20 @@ extern "C" int uv_rmsnorm_rope(const void* x, long ldx, void* out, long ldo, con
     a.L = L; a.C = C; a.D = head_dim; a.F = F; a.Hh = Hh; a.Ww = Ww; a.eps = eps;
     const int c = head_dim / 2;  // model.py:43  split [c - 2*(c//3), c//3, c//3]
     a.nh = c / 3; a.nw = c / 3; a.nf = c - 2 * (c / 3);
-    const dim3 grid((L + 3) / 4), block(256);
+    const int rpw = L >= 4096 ? 4 : 1;
+    const dim3 grid((L + 4 * rpw - 1) / (4 * rpw)), block(256);
     const int chunks = (C + 511) / 512;
-    if (chunks <= 2) hipLaunchKernelGGL(rmsnorm_rope_kernel<2>, grid, block, 0, (hipStream_t)stream, a);
-    else if (chunks <= 8) hipLaunchKernelGGL(rmsnorm_rope_kernel<8>, grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(rmsnorm_rope_kernel<16>, grid, block, 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (rpw == 4) {
+        if (chunks <= 2) hipLaunchKernelGGL((rmsnorm_rope_kernel<2, 4>), grid, block, 0, st, a);
+        else if (chunks <= 6) hipLaunchKernelGGL((rmsnorm_rope_kernel<6, 4>), grid, block, 0, st, a);
+        else if (chunks <= 8) hipLaunchKernelGGL((rmsnorm_rope_kernel<8, 4>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((rmsnorm_rope_kernel<16, 4>), grid, block, 0, st, a);
+    } else {
+        if (chunks <= 2) hipLaunchKernelGGL((rmsnorm_rope_kernel<2, 1>), grid, block, 0, st, a);
+        else if (chunks <= 8) hipLaunchKernelGGL((rmsnorm_rope_kernel<8, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((rmsnorm_rope_kernel<16, 1>), grid, block, 0, st, a);
+    }
     UV_CHECK_LAUNCH("uv_rmsnorm_rope");
     return 0;
 }

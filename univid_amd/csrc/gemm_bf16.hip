@@ -103,6 +103,52 @@ __device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, cons
     }
 }
 
+
+// The fp32 read-modify-write epilogues (x += y, x += y*gate) as a D-deep software pipeline over a wave's NF fragments:
+// the token->gate-row indices of all rows are fetched first, then the x / gate loads of fragment f+D are issued before
+// fragment f is stored. Written in this order by hand because the compiler must assume the x stores alias the later
+// loads and otherwise serialises {index load -> gate/x load -> store} per row block (4-8 dependent HBM round trips per tile).
+template <int EPI, int NF, int D>
+__device__ __forceinline__ void epi_rmw_pipe(const GemmArgs& p, const int (&mb)[NF], const int (&nb)[NF], const f32x4 (&acc)[NF],
+                                             int frow, int fq) {
+    static_assert(EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32, "rmw epilogues only");
+    constexpr bool GATE = EPI == UV_EPI_GATE_RESID_F32;
+    const float* grow[NF];
+    if (GATE) {
+        int t[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) t[f] = p.gate_tid ? p.gate_tid[min(mb[f] + frow, p.M - 1)] : 0;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) grow[f] = p.gate + (long)t[f] * p.gate_stride;
+    }
+    f32x4 xb[D], gb[D];
+    u32x2 bb[D];
+    auto issue = [&](int f, int slot) {
+        const int m = min(mb[f] + frow, p.M - 1), n = min(nb[f] + 4 * fq, p.N - 4);
+        xb[slot] = *(const f32x4*)((const float*)p.out + (long)m * p.ldo + n);
+        if (GATE) gb[slot] = *(const f32x4*)(grow[f] + n);
+        bb[slot] = p.bias ? *(const u32x2*)(p.bias + n) : (u32x2){0u, 0u};
+    };
+#pragma unroll
+    for (int f = 0; f < D && f < NF; ++f) issue(f, f);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int slot = f % D;
+        const int m = mb[f] + frow, n = nb[f] + 4 * fq;
+        float v[4];
+        v[0] = acc[f][0] + bf2f((bf16_t)(bb[slot][0] & 0xffff));
+        v[1] = acc[f][1] + bf2f((bf16_t)(bb[slot][0] >> 16));
+        v[2] = acc[f][2] + bf2f((bf16_t)(bb[slot][1] & 0xffff));
+        v[3] = acc[f][3] + bf2f((bf16_t)(bb[slot][1] >> 16));
+        f32x4 x = xb[slot];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            x[e] = GATE ? __fadd_rn(x[e], __fmul_rn(round_bf(v[e]), gb[slot][e])) : __fadd_rn(x[e], round_bf(v[e]));
+        if (m < p.M && n < p.N) *(f32x4*)((float*)p.out + (long)m * p.ldo + n) = x;
+        if (f + D < NF) issue(f + D, slot);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, int NS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
@@ -259,11 +305,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
     }
 
     // ---- epilogue
+    if constexpr (EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) {
+        constexpr int NF = TM * TN;
+        int mb[NF], nb[NF];
+        f32x4 av[NF];
 #pragma unroll
-    for (int j = 0; j < TM; ++j)
+        for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
-            epi_frag<EPI>(p, m0 + wm * (BM / WM) + j * 16, n0 + wn * (BN / WN) + i * 16, acc[i][j], frow, fq);
+            for (int i = 0; i < TN; ++i) {
+                mb[j * TN + i] = m0 + wm * (BM / WM) + j * 16;
+                nb[j * TN + i] = n0 + wn * (BN / WN) + i * 16;
+                av[j * TN + i] = acc[i][j];
+            }
+        epi_rmw_pipe<EPI, NF, (NF >= 8 ? 4 : 2)>(p, mb, nb, av, frow, fq);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                epi_frag<EPI>(p, m0 + wm * (BM / WM) + j * 16, n0 + wn * (BN / WN) + i * 16, acc[i][j], frow, fq);
+    }
 }
 
 
@@ -411,15 +472,34 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     UV_KTILE(t + 1, 1, 0, false, false)
     if (wr == 0) UV_SB();
 
+    if constexpr (EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) {
+        int mb[32], nb[32];
+        f32x4 av[32];
 #pragma unroll
-    for (int hm = 0; hm < 2; ++hm)
+        for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int hn = 0; hn < 2; ++hn)
+                for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    epi_frag<EPI>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], frow, fq);
+                    for (int i = 0; i < 2; ++i) {
+                        const int f = ((hm * 4 + j) * 2 + hn) * 2 + i;
+                        mb[f] = m0 + hm * 128 + wr * 64 + j * 16;
+                        nb[f] = n0 + hn * 128 + wc * 32 + i * 16;
+                        av[f] = acc[hn][hm][i][j];
+                    }
+        epi_rmw_pipe<EPI, 32, 8>(p, mb, nb, av, frow, fq);
+    } else {
+#pragma unroll
+        for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        epi_frag<EPI>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], frow, fq);
+    }
 }
 
 static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
@@ -543,12 +623,9 @@ extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw,
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
     if (tile_cfg == 0 && M >= 2048 && N >= 1024 && N % 256 == 0 && K % 128 == 0 && K >= 256) {
-        // Large projections: 256x256 tiles, one workgroup per CU. The 8-wave ping-pong kernel is the faster main loop
-        // (clearly so for long K and for the transposed epilogue); the fp32 read-modify-write epilogues run a little
-        // better from the 16-wave kernel at short K. When the tile count is just above a whole number of rounds, the
-        // leftover rows are split off so they do not cost a full extra round.
-        const bool rmw = epilogue == UV_EPI_GATE_RESID_F32 || epilogue == UV_EPI_RESID_F32;
-        const int main_cfg = (rmw && K <= 4096) ? 5 : 7;
+        // Large projections: 256x256 tiles, one workgroup per CU, on the 8-wave ping-pong kernel. When the tile count is
+        // just above a whole number of rounds, the leftover rows are split off so they do not cost a full extra round.
+        const int main_cfg = 7;
         const long tiles = (long)((M + 255) / 256) * (N / 256);
         const long rounds = tiles / num_cus(), rest = tiles - rounds * num_cus();
         if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) return launch_m_split(a, epilogue, main_cfg, s);

@@ -293,7 +293,8 @@ def _vt_scratch(tag, C, batch, L, device):
     if batch > 1 and L % 8:
         raise NotImplementedError(f"stacked samples need a token count divisible by 8 (got {L}); run them one by one")
     cols = (batch - 1) * L + _round_up(L, 64)
-    return _zeros_cached((tag, C, cols, device), (C, cols), BF16, device)
+    # one scratch per stream: forwards running concurrently on different streams must not share it
+    return _zeros_cached((tag, C, cols, device, torch.cuda.current_stream(device).cuda_stream), (C, cols), BF16, device)
 
 
 def _ensure_prepared(mod):
