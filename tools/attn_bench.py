@@ -25,9 +25,9 @@ print(f"attention L{L}: {ms:.3f} ms {4*L*L*C/ms/1e9:.1f} TFLOP/s")
 if os.environ.get("STAMPS"):
     import ctypes
     lib = _lib.load()
-    for nw, extra in ((4, 0), (8, 0), (4, 40000)):
-        nblk = ((L + nw * 32 - 1) // (nw * 32)) * H
-        st = torch.zeros(nblk * nw * 5, dtype=torch.int64, device=dev)
+    for nw, extra in ((4, 0), (42, 0), (43, 0)):
+        nblk = ((L + 255) // 256) * H if nw >= 42 else ((L + nw * 32 - 1) // (nw * 32)) * H
+        st = torch.zeros(nblk * (4 if nw >= 42 else nw) * 5, dtype=torch.int64, device=dev)
         fn = lib.uvdbg_flash_attn_stamps
         fn.argtypes = [ctypes.c_void_p, ctypes.c_long] * 3 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         for _ in range(2):
@@ -38,4 +38,7 @@ if os.environ.get("STAMPS"):
         v = st.view(-1, 5).double()
         tiles = (L + 63) // 64
         per = v.median(0).values / tiles
-        print(f"nw={nw}: median cycles per tile per wave  qk={per[0]:.0f} softmax={per[1]:.0f} pv={per[2]:.0f} commit={per[3]:.0f} barrier={per[4]:.0f} total={per.sum():.0f}")
+        if nw >= 42:
+            print(f"QB=2 sgb={nw == 43}: median cycles per 64-query tile per wave  QK_A+head={per[0]:.0f} QK_B|smA={per[1]:.0f} headB={per[2]:.0f} PV_A|smB={per[3]:.0f} PV_B+wait+barrier={per[4]:.0f} total={per.sum():.0f}")
+        else:
+            print(f"nw={nw}: median cycles per tile per wave  qk={per[0]:.0f} softmax={per[1]:.0f} pv={per[2]:.0f} commit={per[3]:.0f} barrier={per[4]:.0f} total={per.sum():.0f}")

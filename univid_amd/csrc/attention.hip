@@ -26,6 +26,7 @@
 
 #define UV_ATT_QW 32     // queries per wave
 #define UV_ATT_KV 64
+#define UV_ATT_DEFER 8.0f   // log2 of the largest P allowed before the reference maximum is moved
 
 struct AttnArgs {
     const bf16_t* q;   // [Lq, ldq]   head h at column h*128
@@ -47,8 +48,11 @@ __device__ __forceinline__ int perm23(int i) {  // swap bits 2 and 3
 // NW = waves per workgroup: 8 (256 queries, 1 workgroup per CU) or 4 (128 queries, 2 workgroups per CU: the two waves
 // that share a SIMD then belong to DIFFERENT workgroups, are not re-aligned by a common barrier every tile, and drift
 // into complementary phases - one in its MFMA cluster while the other does softmax VALU work).
-template <int D, int NW, bool STAMP = false>
-__global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, unsigned long long* stamps = nullptr) {
+// QB = 32-query blocks per wave. QB = 2 with NW = 4 is the one-wave-per-SIMD form: the wave owns the SIMD's whole 512-entry
+// register file, every K / V^T fragment read from LDS and every LDS-DMA piece serves 64 queries instead of 32, and the
+// softmax VALU work of one block has the other block's MFMAs to hide behind inside the same instruction stream.
+template <int D, int NW, bool STAMP = false, int QB = 1, bool SGB = false>
+__global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kernel(AttnArgs p, unsigned long long* stamps = nullptr) {
     constexpr int NT = NW * 64;
     constexpr int KROW = 2 * D;                 // bytes per K row in LDS (256 or 128)
     constexpr int KCH = D / 8;                  // 16-B chunks per K row
@@ -75,16 +79,17 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
         p.vt += (long)b * p.Lk;
         p.out += b * p.Lq * p.ldo;
     }
-    const int q0w = qb * (NW * UV_ATT_QW) + wave * UV_ATT_QW;
+    const int q0w = qb * (NW * QB * UV_ATT_QW) + wave * (QB * UV_ATT_QW);
     const long hcol = (long)head * D;
 
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane (r,h) holds Q[q0w+r][16kk+8h .. +7]
-    bf16x8 qf[NKK];
-    {
-        const int qrow = min(q0w + r, p.Lq - 1);
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane (r,h) holds Q[q0w+32b+r][16kk+8h .. +7]
+    bf16x8 qf[QB][NKK];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qrow = min(q0w + 32 * b + r, p.Lq - 1);
         const bf16_t* qp = p.q + (long)qrow * p.ldq + hcol + 8 * h;
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
+        for (int kk = 0; kk < NKK; ++kk) qf[b][kk] = *(const bf16x8*)(qp + 16 * kk);
     }
 
     // ---- staging: K and V^T tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction,
@@ -139,13 +144,18 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
     const int v_row_off = K_BYTES + r * 128;
     const int v_key = (r >> 1) & 7;
 
-    f32x16 oacc[ND];
+    f32x16 oacc[QB][ND];
+    float m_run[QB];  // running max of raw scores (both half-waves hold the same value)
+    float l_run[QB];  // this half-wave's partial row sum
 #pragma unroll
-    for (int d = 0; d < ND; ++d)
+    for (int b = 0; b < QB; ++b) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
-    float m_run = -INFINITY;  // running max of raw scores (both half-waves hold the same value)
-    float l_run = 0.f;        // this half-wave's partial row sum
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[b][d][e] = 0.f;
+        m_run[b] = -INFINITY;
+        l_run[b] = 0.f;
+    }
 
     const int nt = (p.Lk + UV_ATT_KV - 1) / UV_ATT_KV;
     fetch(0, 0);
@@ -155,7 +165,9 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
     // vmcnt(1)/vmcnt(0) - which in steady state waits for the K/V prefetch issued a few instructions earlier and
     // exposes a full L2/HBM latency in every tile (seen in the ISA; ~1000 cycles of a 4500-cycle tile).
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]));
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[b][kk]));
     __syncthreads();
 
     // One KV tile. MASKED is a compile-time flag so that the main loop carries no masking code at all (only the ragged
@@ -173,6 +185,182 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
             tprev = tnow;
         }
     };
+    // ---- one-wave-per-SIMD form (QB == 2): the two 32-query blocks A and B of the wave run half a tile apart so that
+    // each block's softmax VALU work has the other block's MFMAs to hide behind, inside ONE instruction stream:
+    //     QK_A | QK_B + softmax_A | PV_A + softmax_B | PV_B
+    // The rescale decision (a rare branch, see below) is taken before the mixed regions so that each of them is one
+    // basic block the scheduler can interleave.
+    // Row sums by MFMA (QB == 2 path): one more accumulator tile per block whose A operand is all ones, so
+    // lacc[b][*] = sum over keys of the bf16 P values (every register of a lane holds the same sum). It replaces 32
+    // v_add_f32 per block and tile - the VALU pipe, not the matrix pipe, is the busy one in the mixed regions.
+    f32x16 lacc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lacc[b][e] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    auto tile2 = [&](int t, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int kv0 = t * UV_ATT_KV;
+        const char* base = smem + (t & 1) * STAGE;
+        if (t + 1 < nt) fetch(kv0 + UV_ATT_KV, (t + 1) & 1);
+        // Q is only ever an MFMA source: keep it in the accumulator half of the register file (legal for MFMA A/B
+        // operands) so that the 256 architectural VGPRs are left to S, P and the fragment reads
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+a"(qf[b][kk]));
+        f32x16 sacc[2][2];
+        bf16x8 pf[2][2][2];
+        auto qk = [&](int b) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[b][T][e] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(base + T * 32 * KROW + k_row_off + (((2 * kk + h) ^ k_key) << 4));
+                    sacc[b][T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][kk], sacc[b][T], 0, 0, 0);
+                }
+            }
+        };
+        // row maximum + the (rare) move of the reference maximum; returns -m_ref * scale
+        auto head = [&](int b) -> float {
+            if (MASKED) {
+#pragma unroll
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (kv0 + perm23(i) >= p.Lk) sacc[b][T][e] = -INFINITY;
+                    }
+            }
+            float mt = sacc[b][0][0];
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sacc[b][T][e]);
+            {   // the other half-wave's maximum: v_permlane32_swap (one VALU op) instead of a ds_bpermute round trip
+                const unsigned u = __builtin_bit_cast(unsigned, mt);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                mt = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+            }
+            // The O accumulators live in the accumulator half of the register file, which no VALU instruction can touch,
+            // so a rescale is three instructions per register. It is therefore deferred: the reference maximum moves only
+            // when a row's maximum outgrows it by more than 2^8 in the exponent domain (P <= 256 instead of <= 1; P, l
+            // and O stay at one common scale, and bf16 / f32 relative precision is scale-invariant), which after the
+            // first tile practically never happens.
+            const float grow = (mt - m_run[b]) * p.scale_log2;      // +inf on the first tile (m_run = -inf)
+            if (__any(grow > 8.0f)) {
+                const float m_new = fmaxf(m_run[b], mt);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * p.scale_log2);
+                float chain = alpha;   // orders the statements below (asm statements are opaque to the scheduler)
+#pragma unroll
+                for (int d = 0; d <= ND; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float tmp;
+                        // leading nops: the last MFMA that wrote this accumulator must have retired (16-pass XDL ->
+                        // accvgpr read); trailing nop: accvgpr write -> MFMA source
+                        if (d < ND)
+                            asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\t"
+                                         "v_accvgpr_write_b32 %0, %1\n\ts_nop 1"
+                                         : "+a"(oacc[b][d][e]), "=&v"(tmp), "+v"(chain));
+                        else
+                            asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\t"
+                                         "v_accvgpr_write_b32 %0, %1\n\ts_nop 1"
+                                         : "+a"(lacc[b][e]), "=&v"(tmp), "+v"(chain));
+                    }
+                asm volatile("" : "+v"(chain));
+                m_run[b] = m_new;
+            }
+            return -m_run[b] * p.scale_log2;
+        };
+        auto expsum = [&](int b, float mneg) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][T][8 * s2 + j], p.scale_log2, mneg));
+                        pf[b][T][s2][j] = (__bf16)pv;
+                    }
+        };
+        auto pv = [&](int b) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 vf =
+                            *(const bf16x8*)(base + d * 32 * 128 + v_row_off + (((4 * T + 2 * s2 + h) ^ v_key) << 4));
+                        oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][T][s2], oacc[b][d], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    lacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[b][T][s2], lacc[b], 0, 0, 0);
+        };
+        // `pin` keeps a block's P fragments from being sunk below the next rescale branch by the IR optimiser (they would
+        // then be computed with no MFMA beside them)
+        auto pin = [&](int b) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : "+v"(pf[b][T][s2]));
+        };
+        // Order within a region, given to the machine scheduler as a pipeline of groups: LDS fragment reads run 6 ahead
+        // of the MFMA that consumes them (one wave per SIMD: nobody else hides the ~128-cycle LDS latency), and the
+        // softmax instructions are dealt out evenly between the MFMAs.
+#define UV_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define UV_PIPE_MFMA_ONLY()                                                   \
+    UV_SGB(0x100, 6);                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { UV_SGB(0x008, 1); UV_SGB(0x100, 1); } \
+    UV_SGB(0x008, 6);
+#define UV_PIPE_MFMA_VALU()                                                   \
+    UV_SGB(0x100, 6);                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { UV_SGB(0x008, 1); UV_SGB(0x100, 1); UV_SGB(0x002, 5); UV_SGB(0x400, 2); } \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { UV_SGB(0x008, 1); UV_SGB(0x002, 5); UV_SGB(0x400, 2); }
+        stamp(-1);
+        qk(0);
+        if (SGB) { UV_PIPE_MFMA_ONLY() }
+        __builtin_amdgcn_sched_barrier(0);
+        const float mnA = head(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMP) { asm volatile("" ::"v"(mnA)); }
+        stamp(0);
+        qk(1);
+        expsum(0, mnA);
+        pin(0);
+        if (SGB) { UV_PIPE_MFMA_VALU() }
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMP) { asm volatile("" ::"v"(sacc[1][1][15])); }
+        stamp(1);
+        const float mnB = head(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMP) { asm volatile("" ::"v"(mnB)); }
+        stamp(2);
+        pv(0);
+        expsum(1, mnB);
+        pin(1);
+        if (SGB) { UV_PIPE_MFMA_VALU() }
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMP) { asm volatile("" ::"a"(oacc[0][ND - 1][15])); }
+        stamp(3);
+        pv(1);
+        if (SGB) { UV_PIPE_MFMA_ONLY() }
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMP) { asm volatile("" ::"a"(oacc[1][ND - 1][15])); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stamp(4);
+    };
+
     auto tile = [&](int t, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int kv0 = t * UV_ATT_KV;
@@ -180,82 +368,124 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
         const char* base = smem + (t & 1) * STAGE;
         if (t + 1 < nt) fetch(kv0 + UV_ATT_KV, (t + 1) & 1);   // other buffer: last read in tile t-1, fenced by its barrier
 
-        // ---- S^T = K . Q^T  (two 32-key tiles)
-        f32x16 sacc[2];
+        // ---- S^T = K . Q^T  (two 32-key tiles) for every 32-query block of the wave
+        f32x16 sacc[QB][2];
 #pragma unroll
-        for (int T = 0; T < 2; ++T) {
+        for (int b = 0; b < QB; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[T][e] = 0.f;
+            for (int T = 0; T < 2; ++T) {
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const bf16x8 kf =
-                    *(const bf16x8*)(base + T * 32 * KROW + k_row_off + (((2 * kk + h) ^ k_key) << 4));
-                sacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sacc[T], 0, 0, 0);
+                for (int e = 0; e < 16; ++e) sacc[b][T][e] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const bf16x8 kf =
+                        *(const bf16x8*)(base + T * 32 * KROW + k_row_off + (((2 * kk + h) ^ k_key) << 4));
+                    sacc[b][T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][kk], sacc[b][T], 0, 0, 0);
+                }
             }
-        }
 
-        if (STAMP) { asm volatile("" ::"v"(sacc[0][0]), "v"(sacc[1][15])); }
+        if (STAMP) { asm volatile("" ::"v"(sacc[0][0][0]), "v"(sacc[QB - 1][1][15])); }
         stamp(0);
-        // ---- mask the ragged last tile with the TRUE key index of each accumulator row
-        if (MASKED) {
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            // ---- mask the ragged last tile with the TRUE key index of each accumulator row
+            if (MASKED) {
+#pragma unroll
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (kv0 + perm23(i) >= p.Lk) sacc[b][T][e] = -INFINITY;
+                    }
+            }
+
+            // ---- online softmax (query on the lane)
+            float mt = sacc[b][0][0];
 #pragma unroll
             for (int T = 0; T < 2; ++T)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (kv0 + perm23(i) >= p.Lk) sacc[T][e] = -INFINITY;
+                for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sacc[b][T][e]);
+            {   // the other half-wave's maximum: v_permlane32_swap (one VALU op) instead of a ds_bpermute round trip
+                const unsigned u = __builtin_bit_cast(unsigned, mt);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                mt = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+            }
+            float mneg;
+            if constexpr (QB == 1) {
+                // The reference maximum m_run moves only when some row's maximum outgrows it by more than 2^UV_ATT_DEFER in
+                // the exponent domain (then P <= 2^UV_ATT_DEFER instead of <= 1 until the next move; P, l and O share one
+                // scale and bf16 / f32 relative precision is scale-invariant). With the exact running maximum about half
+                // of all tiles of a long sequence still see a new maximum in SOME row of the wave and pay the O rescale.
+                const float grow = (mt - m_run[b]) * p.scale_log2;      // +inf on the first tile (m_run = -inf)
+                if (__any(grow > UV_ATT_DEFER)) {
+                    const float m_new = fmaxf(m_run[b], mt);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * p.scale_log2);
+                    l_run[b] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) oacc[b][d][e] *= alpha;
+                    m_run[b] = m_new;
                 }
-        }
+                mneg = -m_run[b] * p.scale_log2;
+            } else {
+                // One wave per SIMD: the O accumulators live in the accumulator half of the register file, which no VALU
+                // instruction can touch, so a rescale is three instructions per register. It is therefore deferred: the
+                // reference maximum moves only when a row's maximum outgrows it by more than 2^8 in the exponent domain
+                // (P <= 256 instead of <= 1; P, l and O all stay at the same scale, bf16/f32 relative precision is
+                // scale-invariant), which after the first tile practically never happens.
+                const float grow = (mt - m_run[b]) * p.scale_log2;      // +inf on the first tile (m_run = -inf)
+                if (__any(grow > UV_ATT_DEFER)) {
+                    const float m_new = fmaxf(m_run[b], mt);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * p.scale_log2);
+                    l_run[b] *= alpha;
+                    float chain = alpha;   // orders the statements below (asm statements are opaque to the scheduler)
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            float tmp;
+                            // leading nops: the last MFMA that wrote this accumulator must have retired (16-pass XDL ->
+                            // accvgpr read); trailing nop: accvgpr write -> MFMA source
+                            asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\t"
+                                         "v_accvgpr_write_b32 %0, %1\n\ts_nop 1"
+                                         : "+a"(oacc[b][d][e]), "=&v"(tmp), "+v"(chain));
+                        }
+                    asm volatile("" : "+v"(chain));
+                    m_run[b] = m_new;
+                }
+                mneg = -m_run[b] * p.scale_log2;
+            }
+            float psum = 0.f;
+            bf16x8 pf[2][2];
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][T][8 * s + j], p.scale_log2, mneg));
+                        psum += pv;
+                        pf[T][s][j] = (__bf16)pv;
+                    }
+            l_run[b] += psum;
+            if (STAMP) { asm volatile("" ::"v"(pf[1][1])); }
+            if (b == QB - 1) stamp(1);
 
-        // ---- online softmax (query on the lane)
-        float mt = sacc[0][0];
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sacc[T][e]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float mneg = -m_new * p.scale_log2;
-        // exact rescale skip: when no row of this wave got a new maximum, alpha == 1 for every lane and the O / l
-        // rescale is the identity (bit-identical result, wave-uniform branch)
-        if (__any(m_new != m_run)) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
-            l_run *= alpha;
+            // ---- O^T += V^T . P^T
 #pragma unroll
             for (int d = 0; d < ND; ++d)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
-            m_run = m_new;
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 vf =
+                            *(const bf16x8*)(base + d * 32 * 128 + v_row_off + (((4 * T + 2 * s + h) ^ v_key) << 4));
+                        oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[T][s], oacc[b][d], 0, 0, 0);
+                    }
         }
-        float psum = 0.f;
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[T][8 * s + j], p.scale_log2, mneg));
-                    psum += pv;
-                    pf[T][s][j] = (__bf16)pv;
-                }
-        l_run += psum;
-        if (STAMP) { asm volatile("" ::"v"(pf[1][1])); }
-        stamp(1);
 
-        // ---- O^T += V^T . P^T
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 vf =
-                        *(const bf16x8*)(base + d * 32 * 128 + v_row_off + (((4 * T + 2 * s + h) ^ v_key) << 4));
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[T][s], oacc[d], 0, 0, 0);
-                }
-
-        if (STAMP) { asm volatile("" ::"v"(oacc[ND - 1][15])); }
+        if (STAMP) { asm volatile("" ::"v"(oacc[QB - 1][ND - 1][15])); }
         stamp(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of tile t+1 has landed in LDS
         stamp(3);
@@ -264,27 +494,37 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p, 
     };
 
     const int nt_full = p.Lk / UV_ATT_KV;
-    for (int t = 0; t < nt_full; ++t) tile(t, std::false_type{});
-    if (nt_full < nt) tile(nt_full, std::true_type{});
+    if constexpr (QB == 2) {
+        for (int t = 0; t < nt_full; ++t) tile2(t, std::false_type{});
+        if (nt_full < nt) tile2(nt_full, std::true_type{});
+    } else {
+        for (int t = 0; t < nt_full; ++t) tile(t, std::false_type{});
+        if (nt_full < nt) tile(nt_full, std::true_type{});
+    }
 
     if (STAMP && stamps && lane == 0) {
         unsigned long long* dst = stamps + ((long)blockIdx.x * NW + wave) * 5;
         for (int i = 0; i < 5; ++i) dst[i] = seg[i];
     }
     // ---- finish: combine the two half-wave sums, normalise, store bf16 rows
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int q = q0w + r;
-    if (q < p.Lq) {
-        bf16_t* op = p.out + (long)q * p.ldo + hcol + 4 * h;
 #pragma unroll
-        for (int d = 0; d < ND; ++d)
+    for (int b = 0; b < QB; ++b) {
+        float l_half = l_run[b];
+        if constexpr (QB == 2) l_half = lacc[b][0];   // MFMA row sums: already complete over all keys (no half-wave split)
+        const float l_tot = QB == 2 ? l_half : l_half + __shfl_xor(l_half, 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q = q0w + 32 * b + r;
+        if (q < p.Lq) {
+            bf16_t* op = p.out + (long)q * p.ldo + hcol + 4 * h;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 o = {pack_bf2(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv),
-                           pack_bf2(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv)};
-                *(u32x2*)(op + 32 * d + 8 * g) = o;
-            }
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 o = {pack_bf2(oacc[b][d][4 * g + 0] * inv, oacc[b][d][4 * g + 1] * inv),
+                               pack_bf2(oacc[b][d][4 * g + 2] * inv, oacc[b][d][4 * g + 3] * inv)};
+                    *(u32x2*)(op + 32 * d + 8 * g) = o;
+                }
+        }
     }
 }
 
@@ -312,11 +552,23 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
         const char* e = getenv("UV_ATTN_WAVES");
         nw = (e && atoi(e) == 8) ? 8 : 4;
     }
-    a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
-    a.scale_log2 = softmax_scale * 1.4426950408889634f;
-    const dim3 grid(a.q_blocks * H * batch), block(nw * 64);
+    static int qb2 = -1;
+    if (qb2 < 0) {
+        const char* e = getenv("UV_ATTN_QB");
+        qb2 = e ? (atoi(e) == 2 ? 1 : (atoi(e) == 3 ? 2 : 0)) : 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* nostamps = nullptr;
+    a.scale_log2 = softmax_scale * 1.4426950408889634f;
+    if (qb2 && head_dim == 128) {   // 4 waves x 64 queries, one wave per SIMD
+        a.q_blocks = (Lq + 255) / 256;
+        if (qb2 == 2) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, false, 2, true>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a, nostamps);
+        else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, false, 2, false>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a, nostamps);
+        UV_CHECK_LAUNCH("uv_flash_attn_bf16");
+        return 0;
+    }
+    a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
+    const dim3 grid(a.q_blocks * H * batch), block(nw * 64);
     if (head_dim == 128 && nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8>), grid, block, 0, st, a, nostamps);
     else if (head_dim == 128) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4>), grid, block, 0, st, a, nostamps);
     else if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 8>), grid, block, 0, st, a, nostamps);
@@ -342,7 +594,12 @@ extern "C" int uvdbg_flash_attn_stamps(const void* q, long ldq, const void* k, l
         hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<128, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
         hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<128, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
     }
-    if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8, true>), grid, block, extra_lds, (hipStream_t)stream, a, stamps);
+    if (nw == 42 || nw == 43) {
+        a.q_blocks = (Lq + 255) / 256;
+        const dim3 g2(a.q_blocks * H), b2(256);
+        if (nw == 42) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true, 2, false>), g2, b2, 0, (hipStream_t)stream, a, stamps);
+        else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true, 2, true>), g2, b2, 0, (hipStream_t)stream, a, stamps);
+    } else if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8, true>), grid, block, extra_lds, (hipStream_t)stream, a, stamps);
     else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true>), grid, block, extra_lds, (hipStream_t)stream, a, stamps);
     UV_CHECK_LAUNCH("uvdbg_flash_attn_stamps");
     return 0;

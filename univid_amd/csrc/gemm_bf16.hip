@@ -37,6 +37,7 @@ struct GemmArgs {
     long lda, ldw, ldo, gate_stride;
     int M, N, K;
     int tiles_m, tiles_n;
+    unsigned long long* dbg;  // diagnostic build only (VAR 2): per-wave cycle sums, see uvdbg_gemm_stamps
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
 #define UV_SB() __builtin_amdgcn_s_barrier()
 #define UV_SCHED() __builtin_amdgcn_sched_barrier(0)
 
-template <int EPI>
+template <int EPI, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     constexpr bool TRANS = (EPI == UV_EPI_BF16_T);
     constexpr int HALF = 16384;      // one half-tile: 128 rows x 128 B
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     char* const my_dst = smem + wave * 1024;
     const int nk = p.K / UV_BK;
 #define UV_STAGE(SRC, KT, DSTOFF)                                         \
-    {                                                                     \
+    if constexpr (VAR != 3) {                                             \
         const bf16_t* g0_ = SRC[0] + (long)(KT) * UV_BK;                  \
         const bf16_t* g1_ = SRC[1] + (long)(KT) * UV_BK;                  \
         glds16(g0_, (lds_void*)(my_dst + (DSTOFF)));                      \
@@ -409,31 +410,42 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4][2], w0[2][2], w1[2][2];
+    if constexpr (VAR == 3) {   // operands never loaded in this experiment: give them finite values
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[j][ks] = *(const bf16x8*)(p.A + (lane + j * 64 + ks * 256) * 8);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { w0[i][ks] = *(const bf16x8*)(p.W + (lane + i * 64 + ks * 128) * 8); w1[i][ks] = w0[i][ks]; }
+    }
 
 #define UV_RD_A(B, H)                                                                             \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+    if constexpr (VAR != 3) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
         af[j][0] = *(const bf16x8*)(la + (B) * BUF + (H) * HALF + j * 2048 + lx);                 \
         af[j][1] = *(const bf16x8*)(la + (B) * BUF + (H) * HALF + j * 2048 + (lx ^ 64));          \
     }
 #define UV_RD_W(B, H, WF)                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
+    if constexpr (VAR != 3) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
         WF[i][0] = *(const bf16x8*)(lw + (B) * BUF + (H) * HALF + i * 2048 + lx);                 \
         WF[i][1] = *(const bf16x8*)(lw + (B) * BUF + (H) * HALF + i * 2048 + (lx ^ 64));          \
     }
-#define UV_MFMA_Q(HM, HN, WF)                                                                     \
-    __builtin_amdgcn_s_setprio(1);                                                                \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+#define UV_MFMA_H(HM, HN, WF, KS)                                                                 \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
         if (TRANS)                                                                                \
-            acc[HN][HM][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][ks], WF[i][ks], acc[HN][HM][i][j], 0, 0, 0); \
+            acc[HN][HM][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][KS], WF[i][KS], acc[HN][HM][i][j], 0, 0, 0); \
         else                                                                                      \
-            acc[HN][HM][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i][ks], af[j][ks], acc[HN][HM][i][j], 0, 0, 0); \
-    }                                                                                             \
+            acc[HN][HM][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i][KS], af[j][KS], acc[HN][HM][i][j], 0, 0, 0); \
+    }
+#define UV_MFMA_Q(HM, HN, WF)                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    UV_MFMA_H(HM, HN, WF, 0) UV_MFMA_H(HM, HN, WF, 1)                                             \
     __builtin_amdgcn_s_setprio(0);
 #define UV_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // one K tile T living in buffer B (the other buffer is O); ST1: K tile T+1 exists, ST2: K tile T+2 exists
-#define UV_KTILE(T, B, O, ST1, ST2)                                                               \
+#define UV_KTILE0(T, B, O, ST1, ST2)                                                              \
     UV_RD_W(B, 0, w0) UV_SCHED(); UV_RD_A(B, 0)                                                   \
     if (ST1) UV_STAGE(a_src[1], (T) + 1, (O) * BUF + HALF)                                        \
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                            \
@@ -455,6 +467,40 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     }                                                                                             \
     UV_SB(); UV_SCHED();                                                                          \
     UV_MFMA_Q(1, 0, w0) UV_SCHED(); UV_SB();
+// VAR 2 (diagnostic): VAR 0's schedule with s_memtime stamps at phase start (S), after the first barrier (B) and before the
+// second barrier (E); values are consumed once per K tile in phase 4, where no LDS read is outstanding.
+#define UV_TS(X) UV_SCHED(); X = __builtin_amdgcn_s_memtime(); UV_SCHED();
+#define UV_KTILE2(T, B, O, ST1, ST2)                                                              \
+    UV_TS(tS[0]) UV_RD_W(B, 0, w0) UV_SCHED(); UV_RD_A(B, 0)                                      \
+    if (ST1) UV_STAGE(a_src[1], (T) + 1, (O) * BUF + HALF)                                        \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                            \
+    UV_SB(); UV_TS(tB[0]) UV_LGKM0(); UV_SCHED();                                                 \
+    UV_MFMA_Q(0, 0, w0) UV_TS(tE[0]) UV_SB();                                                     \
+    UV_TS(tS[1]) UV_RD_W(B, 1, w1)                                                                \
+    if (ST2) UV_STAGE(w_src[0], (T) + 2, (B) * BUF + 2 * HALF)                                    \
+    UV_SB(); UV_TS(tB[1]) UV_LGKM0(); UV_SCHED();                                                 \
+    UV_MFMA_Q(0, 1, w1) UV_TS(tE[1]) UV_SB();                                                     \
+    UV_TS(tS[2]) UV_RD_A(B, 1)                                                                    \
+    if (ST2) UV_STAGE(a_src[0], (T) + 2, (B) * BUF)                                               \
+    UV_SB(); UV_TS(tB[2]) UV_LGKM0(); UV_SCHED();                                                 \
+    UV_MFMA_Q(1, 1, w1) UV_TS(tE[2]) UV_SB();                                                     \
+    UV_TS(tS[3])                                                                                  \
+    if (ST2) {                                                                                    \
+        UV_STAGE(w_src[1], (T) + 2, (B) * BUF + 3 * HALF)                                         \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                          \
+    } else {                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+    }                                                                                             \
+    UV_SB(); UV_TS(tB[3])                                                                         \
+    _Pragma("unroll") for (int ph = 0; ph < 3; ++ph) {                                            \
+        cyc[3 * ph] += tB[ph] - tS[ph]; cyc[3 * ph + 1] += tE[ph] - tB[ph]; cyc[3 * ph + 2] += tS[ph + 1] - tE[ph]; \
+    }                                                                                             \
+    if (have_prev) cyc[11] += tS[0] - tE_prev;                                                    \
+    have_prev = true;                                                                             \
+    UV_MFMA_Q(1, 0, w0) UV_TS(tE[3]) UV_SB();                                                     \
+    cyc[9] += tB[3] - tS[3]; cyc[10] += tE[3] - tB[3]; tE_prev = tE[3];
+#define UV_KTILE(T, B, O, ST1, ST2)                                                               \
+    if constexpr (VAR >= 2) { UV_KTILE2(T, B, O, ST1, ST2) } else { UV_KTILE0(T, B, O, ST1, ST2) }
 
     // prologue: K tile 0 (W0 A0 W1 A1) and W0 A0 W1 of K tile 1; vmcnt(6) = K tile 0 landed
     UV_STAGE(w_src[0], 0, 2 * HALF) UV_STAGE(a_src[0], 0, 0) UV_STAGE(w_src[1], 0, 3 * HALF) UV_STAGE(a_src[1], 0, HALF)
@@ -463,6 +509,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     UV_SB();
     if (wr == 1) UV_SB();  // the second group runs one barrier behind the first
 
+    unsigned long long tS[4], tB[4], tE[4], tE_prev = 0, cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool have_prev = false;
+    const unsigned long long t_begin = VAR >= 2 ? __builtin_amdgcn_s_memtime() : 0;
     int t = 0;
     for (; t + 2 < nk; t += 2) {
         UV_KTILE(t, 0, 1, true, true)
@@ -471,6 +520,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     UV_KTILE(t, 0, 1, true, false)
     UV_KTILE(t + 1, 1, 0, false, false)
     if (wr == 0) UV_SB();
+    if constexpr (VAR >= 2) {
+        if (p.dbg && lane == 0) {
+            unsigned long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 16;
+            for (int i = 0; i < 12; ++i) d[i] = cyc[i];
+            d[12] = __builtin_amdgcn_s_memtime() - t_begin;
+            d[13] = nk;
+        }
+    }
 
     if constexpr (EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) {
         int mb[32], nb[32];
@@ -502,6 +559,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     }
 }
 
+template <int VAR = 0>
 static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
     GemmArgs a = a0;
     a.tiles_m = (a.M + 255) / 256;
@@ -510,7 +568,7 @@ static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
     const size_t lds = 128 * 1024;
 #define UV_LAUNCH8(E)                                                                              \
     case E: {                                                                                      \
-        auto kern = gemm_bf16_8ph_kernel<E>;                                                       \
+        auto kern = gemm_bf16_8ph_kernel<E, VAR>;                                                    \
         static bool attr_set = false;                                                              \
         if (!attr_set) {                                                                           \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
@@ -620,7 +678,7 @@ extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw,
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias_bf16;
     a.out = out; a.gate = gate; a.gate_tid = gate_tid;
     a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.gate_stride = gate_stride;
-    a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
+    a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0; a.dbg = nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (tile_cfg == 0 && M >= 2048 && N >= 1024 && N % 256 == 0 && K % 128 == 0 && K >= 256) {
         // Large projections: 256x256 tiles, one workgroup per CU, on the 8-wave ping-pong kernel. When the tile count is
@@ -666,9 +724,24 @@ static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStrea
         case 13: return launch_cfg<128, 128, 2, 4, 2>(a, epilogue, s);
         case 7:
             UV_CHECK_ARG(K % 128 == 0 && K >= 256, "uv_gemm_bf16_nt: tile_cfg 7 needs K %% 128 == 0 and K >= 256 (K=%d)", K);
-            return launch_8ph(a, epilogue, s);
+            return launch_8ph<0>(a, epilogue, s);
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown tile_cfg %d", tile_cfg);
             return -1;
     }
+}
+
+// Diagnostic (not part of the public ABI, used by tools/gemm_bench.py --stamps): the ping-pong kernel with in-kernel cycle
+// stamps. dbg: [tiles][8 waves][16] u64 = per phase {load part + barrier 1, LDS wait + MFMA issue, barrier 2} cycle sums.
+extern "C" int uvdbg_gemm_stamps(const void* A, long lda, const void* W, long ldw, int M, int N, int K, void* out, long ldo,
+                                 unsigned long long* dbg, int variant, void* stream) {
+    GemmArgs a;
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = nullptr; a.out = out; a.gate = nullptr; a.gate_tid = nullptr;
+    a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.gate_stride = 0; a.M = M; a.N = N; a.K = K; a.dbg = dbg;
+    a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 255) / 256;
+    auto kern = variant == 3 ? gemm_bf16_8ph_kernel<UV_EPI_BF16, 3> : gemm_bf16_8ph_kernel<UV_EPI_BF16, 2>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), 128 * 1024, (hipStream_t)stream, a);
+    UV_CHECK_LAUNCH("uvdbg_gemm_stamps");
+    return 0;
 }
