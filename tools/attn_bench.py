@@ -39,6 +39,6 @@ if os.environ.get("STAMPS"):
         tiles = (L + 63) // 64
         per = v.median(0).values / tiles
         if nw >= 42:
-            print(f"QB=2 sgb={nw == 43}: median cycles per 64-query tile per wave  QK_A+head={per[0]:.0f} QK_B|smA={per[1]:.0f} headB={per[2]:.0f} PV_A|smB={per[3]:.0f} PV_B+wait+barrier={per[4]:.0f} total={per.sum():.0f}")
+            print(f"QB=2 sgb={nw == 43}: median cycles per 64-query tile per wave  step1 QK_A|expB={per[0]:.0f} step2 PV_B1|maxA+decide={per[1]:.0f} step3 PV_B2,QK_B|expA={per[2]:.0f} step4 PV_A1|maxB+decide={per[3]:.0f} step5 PV_A2+wait+barrier={per[4]:.0f} total={per.sum():.0f}")
         else:
             print(f"nw={nw}: median cycles per tile per wave  qk={per[0]:.0f} softmax={per[1]:.0f} pv={per[2]:.0f} commit={per[3]:.0f} barrier={per[4]:.0f} total={per.sum():.0f}")

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
     constexpr int K_BYTES = UV_ATT_KV * KROW;   // 16 KiB at D=128
     constexpr int V_BYTES = D * 128;            // 16 KiB at D=128
     constexpr int STAGE = K_BYTES + V_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[QB == 2 ? 2 * K_BYTES + 3 * V_BYTES : 2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -158,7 +158,22 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
     }
 
     const int nt = (p.Lk + UV_ATT_KV - 1) / UV_ATT_KV;
-    fetch(0, 0);
+    if constexpr (QB == 2) {
+        char* kb = smem;
+        char* vb = smem + 2 * K_BYTES;
+#pragma unroll
+        for (int i = 0; i < K_INSTR; ++i) {
+            const bf16_t* src = ksrc[i] + (long)min(krow[i], p.Lk - 1) * p.ldk;
+            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(kb + (i * NW + wave_u) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < V_INSTR; ++i) {
+            const bf16_t* src = vsrc[i];
+            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(vb + (i * NW + wave_u) * 1024), 16, 0, 0);
+        }
+    } else {
+        fetch(0, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // Pin "every prologue load has landed" BEFORE the loop: vmcnt retires in order, so if the compiler has to assume
     // the Q fragment loads may still be in flight at the loop header it guards their first use inside the loop with
@@ -201,164 +216,200 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    // Software pipeline of the QB == 2 form. Block B runs one tile behind block A, so that every group of MFMAs has
+    // softmax VALU work of the OTHER block to hide (one wave per SIMD: nothing else would):
+    //     step 1   MFMA  S_A(t)  = K(t) Q_A             VALU  P_B(t-1) = exp2(S_B(t-1) ...)
+    //     step 2   MFMA  O_B    += V(t-1) P_B(t-1)  (1st half)      row max of S_A(t)      -> reference-maximum decision A
+    //     step 3   MFMA  O_B (2nd half), S_B(t) = K(t) Q_B          P_A(t) = exp2(S_A(t) ...)
+    //     step 4   MFMA  O_A    += V(t) P_A(t)      (1st half)      row max of S_B(t)      -> decision B
+    //     step 5   MFMA  O_A (2nd half)
+    // V tiles therefore live for two iterations (3-deep V ring, 2-deep K ring). Tile -1 is a dummy: S_B(-1) = -inf
+    // gives P = 0, multiplied into V(0)'s (finite) fragments.
+    f32x16 sB[2];      // S_B of the previous tile
+    float mnegB = 0.f;
+    bf16x8 pB[2][2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sB[T][e] = -INFINITY;
+    const char* const vring = smem + 2 * K_BYTES;
+    int vcur = 0, vprev = 0;   // V ring slots of tile t and t-1
+    auto rowmax = [&](f32x16 (&s_)[2], int kv0, bool masked) -> float {
+        if (masked) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (kv0 + perm23(i) >= p.Lk) s_[T][e] = -INFINITY;
+                }
+        }
+        float mt = s_[0][0];
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mt = fmaxf(mt, s_[T][e]);
+        const unsigned u = __builtin_bit_cast(unsigned, mt);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    };
+    // The O and l accumulators live in the accumulator half of the register file, which no VALU instruction can touch,
+    // so a rescale is three instructions per register; with the deferred reference maximum (UV_ATT_DEFER) it practically
+    // happens on the first tile only. Returns -m_ref * scale.
+    auto decide = [&](int b, float mt) -> float {
+        const float grow = (mt - m_run[b]) * p.scale_log2;      // +inf on the first tile (m_run = -inf)
+        if (__any(grow > UV_ATT_DEFER)) {
+            const float m_new = fmaxf(m_run[b], mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * p.scale_log2);
+            float chain = alpha;   // orders the statements below (asm statements are opaque to the scheduler)
+#pragma unroll
+            for (int d = 0; d <= ND; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float tmp;
+                    // leading nops: the last MFMA that wrote this accumulator must have retired (16-pass XDL ->
+                    // accvgpr read); trailing nop: accvgpr write -> MFMA source
+                    if (d < ND)
+                        asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\t"
+                                     "v_accvgpr_write_b32 %0, %1\n\ts_nop 1"
+                                     : "+a"(oacc[b][d][e]), "=&v"(tmp), "+v"(chain));
+                    else
+                        asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\t"
+                                     "v_accvgpr_write_b32 %0, %1\n\ts_nop 1"
+                                     : "+a"(lacc[b][e]), "=&v"(tmp), "+v"(chain));
+                }
+            asm volatile("" : "+v"(chain));
+            m_run[b] = m_new;
+        }
+        return -m_run[b] * p.scale_log2;
+    };
+    auto expP = [&](f32x16 (&s_)[2], float mneg, bf16x8 (&p_)[2][2]) {
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    p_[T][s2][j] = (__bf16)__builtin_amdgcn_exp2f(__builtin_fmaf(s_[T][8 * s2 + j], p.scale_log2, mneg));
+    };
+    // keeps P from being sunk below the next rescale branch by the IR optimiser (away from the MFMAs it should overlap)
+    auto pinP = [&](bf16x8 (&p_)[2][2]) {
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : "+v"(p_[T][s2]));
+    };
+    auto qk2 = [&](const char* kbase, int b, f32x16 (&s_)[2]) {
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s_[T][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(kbase + T * 32 * KROW + k_row_off + (((2 * kk + h) ^ k_key) << 4));
+                s_[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][kk], s_[T], 0, 0, 0);
+            }
+        }
+    };
+    // half of O^T += V^T P^T: d tiles {2*half, 2*half+1}; the row-sum tile (A operand = ones) rides with the second half
+    auto pv2 = [&](const char* vbase, int b, bf16x8 (&p_)[2][2], int half) {
+#pragma unroll
+        for (int dd = 0; dd < ND / 2; ++dd) {
+            const int d = half * (ND / 2) + dd;
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 vf = *(const bf16x8*)(vbase + d * 32 * 128 + (v_row_off - K_BYTES) + (((4 * T + 2 * s2 + h) ^ v_key) << 4));
+                    oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, p_[T][s2], oacc[b][d], 0, 0, 0);
+                }
+        }
+        if (half == 1) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    lacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p_[T][s2], lacc[b], 0, 0, 0);
+        }
+    };
+    auto fetch2 = [&](int kv0, int kslot, int vslot) {
+        char* kb = smem + kslot * K_BYTES;
+        char* vb = smem + 2 * K_BYTES + vslot * V_BYTES;
+#pragma unroll
+        for (int i = 0; i < K_INSTR; ++i) {
+            const int kr = min(kv0 + krow[i], p.Lk - 1);
+            const bf16_t* src = ksrc[i] + (long)kr * p.ldk;
+            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(kb + (i * NW + wave_u) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < V_INSTR; ++i) {
+            const bf16_t* src = vsrc[i] + kv0;
+            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(vb + (i * NW + wave_u) * 1024), 16, 0, 0);
+        }
+    };
     auto tile2 = [&](int t, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int kv0 = t * UV_ATT_KV;
-        const char* base = smem + (t & 1) * STAGE;
-        if (t + 1 < nt) fetch(kv0 + UV_ATT_KV, (t + 1) & 1);
-        // Q is only ever an MFMA source: keep it in the accumulator half of the register file (legal for MFMA A/B
-        // operands) so that the 256 architectural VGPRs are left to S, P and the fragment reads
+        const char* kbase = smem + (t & 1) * K_BYTES;
+        const char* vb_cur = vring + vcur * V_BYTES;
+        const char* vb_prev = vring + vprev * V_BYTES;
+        const int vnext = vcur == 2 ? 0 : vcur + 1;
+        if (t + 1 < nt) fetch2(kv0 + UV_ATT_KV, (t + 1) & 1, vnext);
+        // Q is only ever an MFMA source: keep it in the accumulator half of the register file (legal for MFMA A/B operands)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+a"(qf[b][kk]));
-        f32x16 sacc[2][2];
-        bf16x8 pf[2][2][2];
-        auto qk = [&](int b) {
-#pragma unroll
-            for (int T = 0; T < 2; ++T) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[b][T][e] = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) {
-                    const bf16x8 kf = *(const bf16x8*)(base + T * 32 * KROW + k_row_off + (((2 * kk + h) ^ k_key) << 4));
-                    sacc[b][T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][kk], sacc[b][T], 0, 0, 0);
-                }
-            }
-        };
-        // row maximum + the (rare) move of the reference maximum; returns -m_ref * scale
-        auto head = [&](int b) -> float {
-            if (MASKED) {
-#pragma unroll
-                for (int T = 0; T < 2; ++T)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int i = 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (kv0 + perm23(i) >= p.Lk) sacc[b][T][e] = -INFINITY;
-                    }
-            }
-            float mt = sacc[b][0][0];
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sacc[b][T][e]);
-            {   // the other half-wave's maximum: v_permlane32_swap (one VALU op) instead of a ds_bpermute round trip
-                const unsigned u = __builtin_bit_cast(unsigned, mt);
-                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                mt = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
-            }
-            // The O accumulators live in the accumulator half of the register file, which no VALU instruction can touch,
-            // so a rescale is three instructions per register. It is therefore deferred: the reference maximum moves only
-            // when a row's maximum outgrows it by more than 2^8 in the exponent domain (P <= 256 instead of <= 1; P, l
-            // and O stay at one common scale, and bf16 / f32 relative precision is scale-invariant), which after the
-            // first tile practically never happens.
-            const float grow = (mt - m_run[b]) * p.scale_log2;      // +inf on the first tile (m_run = -inf)
-            if (__any(grow > 8.0f)) {
-                const float m_new = fmaxf(m_run[b], mt);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * p.scale_log2);
-                float chain = alpha;   // orders the statements below (asm statements are opaque to the scheduler)
-#pragma unroll
-                for (int d = 0; d <= ND; ++d)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float tmp;
-                        // leading nops: the last MFMA that wrote this accumulator must have retired (16-pass XDL ->
-                        // accvgpr read); trailing nop: accvgpr write -> MFMA source
-                        if (d < ND)
-                            asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\t"
-                                         "v_accvgpr_write_b32 %0, %1\n\ts_nop 1"
-                                         : "+a"(oacc[b][d][e]), "=&v"(tmp), "+v"(chain));
-                        else
-                            asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\t"
-                                         "v_accvgpr_write_b32 %0, %1\n\ts_nop 1"
-                                         : "+a"(lacc[b][e]), "=&v"(tmp), "+v"(chain));
-                    }
-                asm volatile("" : "+v"(chain));
-                m_run[b] = m_new;
-            }
-            return -m_run[b] * p.scale_log2;
-        };
-        auto expsum = [&](int b, float mneg) {
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][T][8 * s2 + j], p.scale_log2, mneg));
-                        pf[b][T][s2][j] = (__bf16)pv;
-                    }
-        };
-        auto pv = [&](int b) {
-#pragma unroll
-            for (int d = 0; d < ND; ++d)
-#pragma unroll
-                for (int T = 0; T < 2; ++T)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const bf16x8 vf =
-                            *(const bf16x8*)(base + d * 32 * 128 + v_row_off + (((4 * T + 2 * s2 + h) ^ v_key) << 4));
-                        oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][T][s2], oacc[b][d], 0, 0, 0);
-                    }
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-                    lacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[b][T][s2], lacc[b], 0, 0, 0);
-        };
-        // `pin` keeps a block's P fragments from being sunk below the next rescale branch by the IR optimiser (they would
-        // then be computed with no MFMA beside them)
-        auto pin = [&](int b) {
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : "+v"(pf[b][T][s2]));
-        };
-        // Order within a region, given to the machine scheduler as a pipeline of groups: LDS fragment reads run 6 ahead
-        // of the MFMA that consumes them (one wave per SIMD: nobody else hides the ~128-cycle LDS latency), and the
-        // softmax instructions are dealt out evenly between the MFMAs.
-#define UV_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define UV_PIPE_MFMA_ONLY()                                                   \
-    UV_SGB(0x100, 6);                                                         \
-    _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { UV_SGB(0x008, 1); UV_SGB(0x100, 1); } \
-    UV_SGB(0x008, 6);
-#define UV_PIPE_MFMA_VALU()                                                   \
-    UV_SGB(0x100, 6);                                                         \
-    _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { UV_SGB(0x008, 1); UV_SGB(0x100, 1); UV_SGB(0x002, 5); UV_SGB(0x400, 2); } \
-    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { UV_SGB(0x008, 1); UV_SGB(0x002, 5); UV_SGB(0x400, 2); }
+        f32x16 sA[2];
+        bf16x8 pA[2][2];
         stamp(-1);
-        qk(0);
-        if (SGB) { UV_PIPE_MFMA_ONLY() }
+        // step 1
+        qk2(kbase, 0, sA);
+        expP(sB, mnegB, pB);
+        pinP(pB);
         __builtin_amdgcn_sched_barrier(0);
-        const float mnA = head(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { asm volatile("" ::"v"(mnA)); }
+        if (STAMP) { asm volatile("" ::"v"(sA[1][15])); }
         stamp(0);
-        qk(1);
-        expsum(0, mnA);
-        pin(0);
-        if (SGB) { UV_PIPE_MFMA_VALU() }
+        // step 2
+        pv2(vb_prev, 1, pB, 0);
+        const float mtA = rowmax(sA, kv0, MASKED);
         __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { asm volatile("" ::"v"(sacc[1][1][15])); }
+        const float mnegA = decide(0, mtA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMP) { asm volatile("" ::"v"(mnegA)); }
         stamp(1);
-        const float mnB = head(1);
+        // step 3
+        pv2(vb_prev, 1, pB, 1);
+        qk2(kbase, 1, sB);
+        expP(sA, mnegA, pA);
+        pinP(pA);
         __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { asm volatile("" ::"v"(mnB)); }
+        if (STAMP) { asm volatile("" ::"v"(sB[1][15])); }
         stamp(2);
-        pv(0);
-        expsum(1, mnB);
-        pin(1);
-        if (SGB) { UV_PIPE_MFMA_VALU() }
+        // step 4
+        pv2(vb_cur, 0, pA, 0);
+        const float mtB = rowmax(sB, kv0, MASKED);
+        __builtin_amdgcn_sched_barrier(0);
+        mnegB = decide(1, mtB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMP) { asm volatile("" ::"v"(mnegB)); }
+        stamp(3);
+        // step 5
+        pv2(vb_cur, 0, pA, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (STAMP) { asm volatile("" ::"a"(oacc[0][ND - 1][15])); }
-        stamp(3);
-        pv(1);
-        if (SGB) { UV_PIPE_MFMA_ONLY() }
-        __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { asm volatile("" ::"a"(oacc[1][ND - 1][15])); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         stamp(4);
+        vprev = vcur;
+        vcur = vnext;
+    };
+    // drains block B's last tile after the loop
+    auto tail2 = [&]() {
+        const char* vb_prev = vring + vprev * V_BYTES;
+        expP(sB, mnegB, pB);
+        pv2(vb_prev, 1, pB, 0);
+        pv2(vb_prev, 1, pB, 1);
     };
 
     auto tile = [&](int t, auto masked_tag) {
@@ -497,6 +548,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
     if constexpr (QB == 2) {
         for (int t = 0; t < nt_full; ++t) tile2(t, std::false_type{});
         if (nt_full < nt) tile2(nt_full, std::true_type{});
+        tail2();
     } else {
         for (int t = 0; t < nt_full; ++t) tile(t, std::false_type{});
         if (nt_full < nt) tile(nt_full, std::true_type{});
