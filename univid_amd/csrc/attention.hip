@@ -135,6 +135,31 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
         }
     };
 
+    // Running source pointers for tiles that lie completely inside [0, Lk): no row clamp, one 64-bit add per LDS-DMA
+    // instruction (the clamped form above costs ~7 VALU instructions per piece, ~250 cycles per tile and wave).
+    const bf16_t* kptr[K_INSTR];
+    const bf16_t* vptr[V_INSTR];
+#pragma unroll
+    for (int i = 0; i < K_INSTR; ++i) kptr[i] = ksrc[i] + (long)(UV_ATT_KV + krow[i]) * p.ldk;   // tile 1
+#pragma unroll
+    for (int i = 0; i < V_INSTR; ++i) vptr[i] = vsrc[i] + UV_ATT_KV;
+    const long kstep = (long)UV_ATT_KV * p.ldk;
+    auto fetch_next_full = [&](int buf) {   // tiles 1, 2, ... in order
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < K_INSTR; ++i) {
+            const bf16_t* src = kptr[i];
+            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(base + (i * NW + wave_u) * 1024), 16, 0, 0);
+            kptr[i] += kstep;
+        }
+#pragma unroll
+        for (int i = 0; i < V_INSTR; ++i) {
+            const bf16_t* src = vptr[i];
+            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(base + K_BYTES + (i * NW + wave_u) * 1024), 16, 0, 0);
+            vptr[i] += UV_ATT_KV;
+        }
+    };
+
     // fragment read offsets
     //   K  : LDS row 32T + r, logical chunk 2kk + h, phys = chunk ^ (row & 15) on 256-B rows (D=128),
     //        chunk ^ ((row>>1)&7) on 128-B rows (D=64); both keys depend on r only
@@ -158,6 +183,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
     }
 
     const int nt = (p.Lk + UV_ATT_KV - 1) / UV_ATT_KV;
+    const int nt_full = p.Lk / UV_ATT_KV;
     if constexpr (QB == 2) {
         char* kb = smem;
         char* vb = smem + 2 * K_BYTES;
@@ -188,7 +214,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
     // One KV tile. MASKED is a compile-time flag so that the main loop carries no masking code at all (only the ragged
     // last tile is instantiated with it).
     // diagnostic build only (STAMP): per-segment cycle sums [qk, softmax, pv, commit, barrier] per wave
-    unsigned long long seg[5] = {0, 0, 0, 0, 0};
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
     auto stamp = [&](int which) {
         if (STAMP) {
@@ -412,12 +438,22 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
         pv2(vb_prev, 1, pB, 1);
     };
 
-    auto tile = [&](int t, auto masked_tag) {
+    // FETCH: 1 = the next tile is a full one (running pointers, no branch: the LDS-DMA instructions then sit in the same
+    // scheduling region as the QK MFMAs and are dealt out between them), 0 = decide at run time (last full tile / ragged tile)
+    auto tile = [&](int t, auto masked_tag, auto fetch_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool FETCH_FAST = decltype(fetch_tag)::value;
         const int kv0 = t * UV_ATT_KV;
         stamp(-1);
         const char* base = smem + (t & 1) * STAGE;
-        if (t + 1 < nt) fetch(kv0 + UV_ATT_KV, (t + 1) & 1);   // other buffer: last read in tile t-1, fenced by its barrier
+        // other buffer: last read in tile t-1, fenced by its barrier
+        if constexpr (FETCH_FAST) {
+            fetch_next_full((t + 1) & 1);
+        } else {
+            if (t + 1 < nt_full) fetch_next_full((t + 1) & 1);
+            else if (t + 1 < nt) fetch(kv0 + UV_ATT_KV, (t + 1) & 1);   // the ragged last tile: clamped rows
+        }
+        stamp(5);
 
         // ---- S^T = K . Q^T  (two 32-key tiles) for every 32-query block of the wave
         f32x16 sacc[QB][2];
@@ -435,6 +471,16 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
                 }
             }
 
+        if constexpr (SGB && D == 128 && QB == 1) {   // fragment reads 6 ahead of the MFMA that consumes them
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int i_ = 0; i_ < 10; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (STAMP) { asm volatile("" ::"v"(sacc[0][0][0]), "v"(sacc[QB - 1][1][15])); }
         stamp(0);
 #pragma unroll
@@ -524,6 +570,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
             if (b == QB - 1) stamp(1);
 
             // ---- O^T += V^T . P^T
+            if constexpr (SGB && D == 128 && QB == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int d = 0; d < ND; ++d)
 #pragma unroll
@@ -536,6 +583,16 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
                     }
         }
 
+        if constexpr (SGB && D == 128 && QB == 1) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 1);
+#pragma unroll
+            for (int i_ = 0; i_ < 10; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (STAMP) { asm volatile("" ::"v"(oacc[QB - 1][ND - 1][15])); }
         stamp(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of tile t+1 has landed in LDS
@@ -544,19 +601,19 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
         stamp(4);
     };
 
-    const int nt_full = p.Lk / UV_ATT_KV;
     if constexpr (QB == 2) {
         for (int t = 0; t < nt_full; ++t) tile2(t, std::false_type{});
         if (nt_full < nt) tile2(nt_full, std::true_type{});
         tail2();
     } else {
-        for (int t = 0; t < nt_full; ++t) tile(t, std::false_type{});
-        if (nt_full < nt) tile(nt_full, std::true_type{});
+        for (int t = 0; t + 1 < nt_full; ++t) tile(t, std::false_type{}, std::true_type{});
+        if (nt_full > 0) tile(nt_full - 1, std::false_type{}, std::false_type{});
+        if (nt_full < nt) tile(nt_full, std::true_type{}, std::false_type{});
     }
 
     if (STAMP && stamps && lane == 0) {
-        unsigned long long* dst = stamps + ((long)blockIdx.x * NW + wave) * 5;
-        for (int i = 0; i < 5; ++i) dst[i] = seg[i];
+        unsigned long long* dst = stamps + ((long)blockIdx.x * NW + wave) * 6;
+        for (int i = 0; i < 6; ++i) dst[i] = seg[i];
     }
     // ---- finish: combine the two half-wave sums, normalise, store bf16 rows
 #pragma unroll
@@ -621,7 +678,10 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
     }
     a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
     const dim3 grid(a.q_blocks * H * batch), block(nw * 64);
+    static int sgb1 = -1;
+    if (sgb1 < 0) { const char* e = getenv("UV_ATTN_SGB"); sgb1 = (e && atoi(e) == 0) ? 0 : 1; }   // A/B knob, default on
     if (head_dim == 128 && nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8>), grid, block, 0, st, a, nostamps);
+    else if (head_dim == 128 && sgb1) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, false, 1, true>), grid, block, 0, st, a, nostamps);
     else if (head_dim == 128) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4>), grid, block, 0, st, a, nostamps);
     else if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 8>), grid, block, 0, st, a, nostamps);
     else hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 4>), grid, block, 0, st, a, nostamps);
@@ -651,6 +711,9 @@ extern "C" int uvdbg_flash_attn_stamps(const void* q, long ldq, const void* k, l
         const dim3 g2(a.q_blocks * H), b2(256);
         if (nw == 42) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true, 2, false>), g2, b2, 0, (hipStream_t)stream, a, stamps);
         else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true, 2, true>), g2, b2, 0, (hipStream_t)stream, a, stamps);
+    } else if (nw == 44) {
+        a.q_blocks = (Lq + 127) / 128;
+        hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true, 1, true>), dim3(a.q_blocks * H), dim3(256), 0, (hipStream_t)stream, a, stamps);
     } else if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8, true>), grid, block, extra_lds, (hipStream_t)stream, a, stamps);
     else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true>), grid, block, extra_lds, (hipStream_t)stream, a, stamps);
     UV_CHECK_LAUNCH("uvdbg_flash_attn_stamps");
