@@ -173,6 +173,24 @@ def test_gemm_bf16_pingpong_ring_split(M, N, K, cfgs):
         assert (outT[:, M:] == 0).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(22880, 3072, 3072), (2300, 2048, 640)])
+def test_gemm_schedules_bit_identical(M, N, K):
+    """Race screen at full size: the default ping-pong schedule (7), the 4-phase reference schedule (14), the leftover-row
+    split (8) and the 16-wave kernel (5) accumulate in the same K order, so their FULL outputs must agree bit for bit; an LDS
+    hazard (fragment read before its DMA landed, half-tile restaged too early) would show as a mismatching tile."""
+    from univid_amd._lib import EPI_BF16
+    g = torch.Generator(device=DEV).manual_seed(3)
+    a = (torch.rand(M, K, device=DEV, generator=g) * 2 - 1).to(BF16)
+    w = ((torch.rand(N, K, device=DEV, generator=g) * 2 - 1) * 0.05).to(BF16)
+    ref = torch.zeros(M, N, device=DEV, dtype=BF16)
+    L().gemm_bf16(a, w, None, ref, EPI_BF16, tile_cfg=5)
+    for rep in range(3):
+        for cfg in (7, 14, 8, 0):
+            out = torch.zeros(M, N, device=DEV, dtype=BF16)
+            L().gemm_bf16(a, w, None, out, EPI_BF16, tile_cfg=cfg)
+            assert torch.equal(out, ref), f"cfg {cfg} rep {rep}: {int((out != ref).sum())} elements differ"
+
+
 def test_gemm_rejects_bad_shapes():
     from univid_amd._lib import EPI_BF16, UnividHipError
     a = torch.zeros(8, 48, dtype=BF16, device=DEV)
