@@ -751,3 +751,68 @@ def test_full_size_attention_and_gemm_properties():
     truth = (q[rows].double() @ w.double().t())
     d = (y[rows].double() - truth).abs()
     assert (d <= bf16_ulp(truth.float()).double() + 1e-6).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json's full size (49-frame 704x1280 latent, L = 11 440 tokens, TI2V-5B widths): size-independent properties
+# ---------------------------------------------------------------------------------------------------------------
+def test_full_size_attention_properties():
+    """Self-attention at the bench shape (L = 11 440, 24 heads x 128, cond+uncond stacked): sampled query rows against an fp64
+    softmax computed here, V = 1 gives exactly 1, and attention is linear in V."""
+    Lq = Lk = 11440
+    H, D, B = 24, 128, 2
+    C = H * D
+    g = torch.Generator(device=DEV).manual_seed(21)
+    q = torch.randn(B * Lq, C, device=DEV, generator=g).to(BF16)
+    k = torch.randn(B * Lk, C, device=DEV, generator=g).to(BF16)
+    v = torch.randn(B * Lk, C, device=DEV, generator=g).to(BF16)
+    cols = (B - 1) * Lk + (Lk + 63) // 64 * 64
+    vt = torch.zeros(C, cols, dtype=BF16, device=DEV)
+    vt[:, :B * Lk] = v.t()
+    out = torch.empty(B * Lq, C, dtype=BF16, device=DEV)
+    L().flash_attn(q, k, vt, out, Lq, Lk, H, D, D ** -0.5, batch=B)
+    assert torch.isfinite(out.float()).all()
+    rows = torch.tensor([0, 1, 31, 32, 255, 256, 5000, 11439], device=DEV)
+    for b in range(B):
+        for hd in (0, 11, 23):
+            sl = slice(hd * D, (hd + 1) * D)
+            qs = q[b * Lq + rows][:, sl].double()
+            ks, vs = k[b * Lk:(b + 1) * Lk, sl].double(), v[b * Lk:(b + 1) * Lk, sl].double()
+            truth = torch.softmax(qs @ ks.t() / math.sqrt(D), -1) @ vs
+            got = out[b * Lq + rows][:, sl].double()
+            tol = 3 * bf16_ulp(truth.float().cpu()).to(DEV) + 2e-3 * truth.abs().max()
+            assert ((got - truth).abs() <= tol).all(), f"sample {b} head {hd}: max err {float((got - truth).abs().max()):.3e}"
+    ones = torch.ones_like(vt)
+    o1 = torch.empty_like(out)
+    L().flash_attn(q, k, ones, o1, Lq, Lk, H, D, D ** -0.5, batch=B)
+    assert (o1.float() - 1).abs().max() <= 2 ** -7
+    vt2 = (vt.float() * 0.5).to(BF16)                       # exact scaling: attention is linear in V
+    o2 = torch.empty_like(out)
+    L().flash_attn(q, k, vt2, o2, Lq, Lk, H, D, D ** -0.5, batch=B)
+    assert ((o2.float() * 2 - out.float()).abs() <= 2 * bf16_ulp(out.float().cpu()).to(DEV)).all()
+
+
+def test_full_size_dit_stack_equals_sequential():
+    """Two TI2V-5B-width blocks at the bench sequence length: the stacked CFG pair is bit-identical to two single forwards,
+    everything finite, and the result depends on the context (cond != uncond)."""
+    from univid_amd.wan.model import WanModel
+    from univid_amd.wan.textimage2video import TI2VConfig
+    cfg = dict(TI2VConfig.dit, num_layers=2)
+    with torch.device(DEV):
+        m = WanModel.from_config(cfg)
+    m = m.eval().requires_grad_(False)
+    m.init_weights(5)
+    m.prepare()
+    g = torch.Generator(device=DEV).manual_seed(4)
+    lat = torch.randn(48, 13, 44, 80, device=DEV, generator=g)
+    ca = torch.randn(77, cfg["text_dim"], device=DEV, generator=g) * 0.1
+    cb = torch.randn(12, cfg["text_dim"], device=DEV, generator=g) * 0.1
+    Ltok = 13 * 22 * 40
+    tv = torch.full((1, Ltok), 431.0, device=DEV)
+    with torch.no_grad():
+        both = m([lat, lat], t=torch.cat([tv, tv]), context=[ca, cb], seq_len=Ltok)
+        a = m([lat], t=tv, context=[ca], seq_len=Ltok)[0]
+        b = m([lat], t=tv, context=[cb], seq_len=Ltok)[0]
+    assert both[0].shape == (48, 13, 44, 80) and torch.isfinite(both[0]).all() and torch.isfinite(both[1]).all()
+    assert torch.equal(both[0], a) and torch.equal(both[1], b)
+    assert not torch.equal(a, b)
