@@ -24,12 +24,14 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = dbg.view(tiles, 8, 16).double().cpu()
 nk = K // 64
-names = ["P1 load+b1", "P1 lds+mfma", "P1 b2", "P2 load+b1", "P2 lds+mfma", "P2 b2", "P3 load+b1", "P3 lds+mfma", "P3 b2",
+variant = int(os.environ.get('VARIANT', 2))
+names6 = ["A load+waits", "A barrier1", "A mfma(32)", "A barrier2", "B load+waits", "B barrier1", "B mfma(32)", "B barrier2", "-", "-", "-", "-"]
+names = names6 if variant == 6 else ["P1 load+b1", "P1 lds+mfma", "P1 b2", "P2 load+b1", "P2 lds+mfma", "P2 b2", "P3 load+b1", "P3 lds+mfma", "P3 b2",
          "P4 load+vm+b1", "P4 mfma", "P4 b2"]
 for grp, sl in (("group 0 (waves 0-3)", slice(0, 4)), ("group 1 (waves 4-7)", slice(4, 8))):
     x = d[:, sl, :].reshape(-1, 16)
     per = x[:, :12].median(0).values / nk
-    print(grp, " loop cycles/K-tile %.0f" % (x[:, 12].median().item() / nk))
+    print(grp, " loop cycles/K-tile %.0f" % (x[:, 12].median().item() / nk), " in-kernel clock %.2f GHz" % (x[:, 12].median().item() / max(x[:, 14].median().item(), 1) * 0.1))
     for n, v in zip(names, per):
         print(f"   {n:16s} {v.item():7.1f}")
     print("   sum %.0f" % per.sum().item())

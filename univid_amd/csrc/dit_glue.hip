@@ -8,6 +8,9 @@
 //   patch_embedding im2col / unpatchify   model.py:448-451, 499-522
 //   sinusoidal_embedding_1d + time MLPs   model.py:14-24, 384-386, 460-469
 #include "common.h"
+#ifndef UV_LN_NT
+#define UV_LN_NT 1
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm (no affine, eps) over C, then one of:
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(LnArgs p) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i)
             if (i < nv) {
-                v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
+                v[i] = UV_LN_NT ? __builtin_nontemporal_load((const f32x4*)(xr + (i * 64 + lane) * 4)) : *(const f32x4*)(xr + (i * 64 + lane) * 4);
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
         const int t = (p.mode == 1 && p.tid) ? __builtin_amdgcn_readfirstlane(p.tid[row]) : 0;
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(LnArgs p) {
                 }
                 if (p.out_bf16) {
                     u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-                    *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;
+                    if (UV_LN_NT) __builtin_nontemporal_store(o, (u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c));
+                    else *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;
                 } else {
                     *(f32x4*)((float*)p.out + (long)row * p.ldo + c) = y;
                 }

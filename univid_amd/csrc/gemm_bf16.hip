@@ -533,10 +533,43 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     have_prev = true;                                                                             \
     UV_MFMA_Q(1, 0, w0) UV_TS(tE[3]) UV_SB();                                                     \
     cyc[9] += tB[3] - tS[3]; cyc[10] += tE[3] - tB[3]; tE_prev = tE[3];
+// VAR 6 (diagnostic): VAR 5's schedule with stamps: per phase {load part incl. waits, barrier 1, MFMA cluster, barrier 2}
+#define UV_KTILE6(T, B, O, ST1, ST2)                                                              \
+    UV_TS(tS[0]) UV_RD_W(B, 0, w0) UV_RD_W(B, 1, w1) UV_RD_A(B, 0)                                \
+    if (ST1) {                                                                                    \
+        UV_STAGE(a_src[1], (T) + 1, (O) * BUF + HALF)                                             \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
+    } else {                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+    }                                                                                             \
+    UV_LGKM0(); UV_TS(tS[1]) UV_SB(); UV_TS(tB[0])                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    UV_MFMA_H(0, 0, w0, 0) UV_MFMA_H(0, 0, w0, 1) UV_MFMA_H(0, 1, w1, 0) UV_MFMA_H(0, 1, w1, 1)   \
+    __builtin_amdgcn_s_setprio(0); UV_TS(tE[0]) UV_SB();                                          \
+    UV_TS(tS[2]) UV_RD_A(B, 1)                                                                    \
+    if (ST2) {                                                                                    \
+        UV_STAGE(w_src[0], (T) + 2, (B) * BUF + 2 * HALF)                                         \
+        UV_STAGE(w_src[1], (T) + 2, (B) * BUF + 3 * HALF)                                         \
+        UV_STAGE(a_src[0], (T) + 2, (B) * BUF)                                                    \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
+    } else if (ST1) {                                                                             \
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                          \
+    } else {                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+    }                                                                                             \
+    UV_LGKM0(); UV_TS(tS[3]) UV_SB(); UV_TS(tB[1])                                                \
+    cyc[0] += tS[1] - tS[0]; cyc[1] += tB[0] - tS[1]; cyc[2] += tE[0] - tB[0]; cyc[3] += tS[2] - tE[0]; \
+    cyc[4] += tS[3] - tS[2]; cyc[5] += tB[1] - tS[3];                                             \
+    if (have_prev) { cyc[6] += tE_prev - tB_prev; cyc[7] += tS[0] - tE_prev; }                    \
+    have_prev = true;                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    UV_MFMA_H(1, 1, w1, 0) UV_MFMA_H(1, 1, w1, 1) UV_MFMA_H(1, 0, w0, 0) UV_MFMA_H(1, 0, w0, 1)   \
+    __builtin_amdgcn_s_setprio(0); UV_TS(tE[1]) UV_SB();                                          \
+    tE_prev = tE[1]; tB_prev = tB[1];
 #define UV_KTILE(T, B, O, ST1, ST2)                                                               \
-    if constexpr (VAR == 5) { UV_KTILE5(T, B, O, ST1, ST2) } else if constexpr (VAR >= 2) { UV_KTILE2(T, B, O, ST1, ST2) } else { UV_KTILE0(T, B, O, ST1, ST2) }
+    if constexpr (VAR == 6) { UV_KTILE6(T, B, O, ST1, ST2) } else if constexpr (VAR == 5) { UV_KTILE5(T, B, O, ST1, ST2) } else if constexpr (VAR >= 2) { UV_KTILE2(T, B, O, ST1, ST2) } else { UV_KTILE0(T, B, O, ST1, ST2) }
 
-    if constexpr (VAR == 5) {
+    if constexpr (VAR == 5 || VAR == 6) {
         // prologue: W0 W1 A0 A1 of K tile 0, W0 W1 A0 of K tile 1; vmcnt(8) = W0 W1 A0 of K tile 0 landed
         UV_STAGE(w_src[0], 0, 2 * HALF) UV_STAGE(w_src[1], 0, 3 * HALF) UV_STAGE(a_src[0], 0, 0) UV_STAGE(a_src[1], 0, HALF)
         UV_STAGE(w_src[0], 1, BUF + 2 * HALF) UV_STAGE(w_src[1], 1, BUF + 3 * HALF) UV_STAGE(a_src[0], 1, BUF)
@@ -550,9 +583,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     UV_SB();
     if (wr == 1) UV_SB();  // the second group runs one barrier behind the first
 
-    unsigned long long tS[4], tB[4], tE[4], tE_prev = 0, cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tS[4], tB[4], tE[4], tE_prev = 0, tB_prev = 0, cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool have_prev = false;
     const unsigned long long t_begin = VAR >= 2 ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long r_begin = VAR >= 2 ? __builtin_amdgcn_s_memrealtime() : 0;
     int t = 0;
     for (; t + 2 < nk; t += 2) {
         UV_KTILE(t, 0, 1, true, true)
@@ -566,6 +600,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
             unsigned long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 16;
             for (int i = 0; i < 12; ++i) d[i] = cyc[i];
             d[12] = __builtin_amdgcn_s_memtime() - t_begin;
+            d[14] = __builtin_amdgcn_s_memrealtime() - r_begin;   // 100 MHz ticks: clock = d[12] / d[14] * 100 MHz
             d[13] = nk;
         }
     }
@@ -781,7 +816,7 @@ extern "C" int uvdbg_gemm_stamps(const void* A, long lda, const void* W, long ld
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = nullptr; a.out = out; a.gate = nullptr; a.gate_tid = nullptr;
     a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.gate_stride = 0; a.M = M; a.N = N; a.K = K; a.dbg = dbg;
     a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 255) / 256;
-    auto kern = variant == 3 ? gemm_bf16_8ph_kernel<UV_EPI_BF16, 3> : gemm_bf16_8ph_kernel<UV_EPI_BF16, 2>;
+    auto kern = variant == 3 ? gemm_bf16_8ph_kernel<UV_EPI_BF16, 3> : variant == 6 ? gemm_bf16_8ph_kernel<UV_EPI_BF16, 6> : gemm_bf16_8ph_kernel<UV_EPI_BF16, 2>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), 128 * 1024, (hipStream_t)stream, a);
     UV_CHECK_LAUNCH("uvdbg_gemm_stamps");
