@@ -35,3 +35,14 @@ for grp, sl in (("group 0 (waves 0-3)", slice(0, 4)), ("group 1 (waves 4-7)", sl
     for n, v in zip(names, per):
         print(f"   {n:16s} {v.item():7.1f}")
     print("   sum %.0f" % per.sum().item())
+
+x = d.reshape(-1, 16)
+print("per workgroup (100 MHz ticks -> us): prologue %.2f us, loop %.2f us, epilogue+drain %.2f us" % (
+    x[:, 8].median().item() / 100, x[:, 14].median().item() / 100, x[:, 9].median().item() / 100))
+ent, end = d[:, 0, 11], d[:, 0, 10]
+print("kernel span %.1f us; workgroup lifetime median %.1f us; %d tiles on %d CUs" % ((end.max() - ent.min()).item() / 100,
+      (end - ent).median().item() / 100, tiles, torch.cuda.get_device_properties(0).multi_processor_count))
+order = torch.argsort(ent)
+starts = (ent[order] - ent.min()) / 100
+print("entry time of the 1st/256th/257th/512th/last workgroup: %.1f %.1f %.1f %.1f %.1f us" % (
+    starts[0].item(), starts[min(255, tiles - 1)].item(), starts[min(256, tiles - 1)].item(), starts[min(511, tiles - 1)].item(), starts[-1].item()))

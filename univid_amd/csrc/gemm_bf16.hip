@@ -353,6 +353,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     constexpr int HALF = 16384;      // one half-tile: 128 rows x 128 B
     constexpr int BUF = 4 * HALF;    // A[0] A[1] W[0] W[1]
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned long long r_entry = VAR >= 2 ? __builtin_amdgcn_s_memrealtime() : 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -602,8 +603,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
             d[12] = __builtin_amdgcn_s_memtime() - t_begin;
             d[14] = __builtin_amdgcn_s_memrealtime() - r_begin;   // 100 MHz ticks: clock = d[12] / d[14] * 100 MHz
             d[13] = nk;
+            d[8] = r_begin - r_entry;                                  // prologue, 100 MHz ticks
+            d[11] = r_entry;                                           // absolute entry time (dispatch skew between workgroups)
         }
     }
+    const unsigned long long r_loop_end = VAR >= 2 ? __builtin_amdgcn_s_memrealtime() : 0;
 
     if constexpr (EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) {
         int mb[32], nb[32];
@@ -632,6 +636,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
                         epi_frag<EPI>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], frow, fq);
+    }
+    if constexpr (VAR >= 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.dbg && lane == 0) {
+            unsigned long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 16;
+            const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
+            d[9] = r_end - r_loop_end;                                 // epilogue incl. store drain, 100 MHz ticks
+            d[10] = r_end;                                             // absolute end time
+        }
     }
 }
 
