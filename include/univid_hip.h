@@ -69,10 +69,11 @@ int uv_layernorm_mod(const float* x, long ldx, void* out, long ldo, int L, int C
                      int round_ln, int out_bf16, void* stream);
 
 /* out = bf16( RoPE( float(bf16(x * rsqrt(mean(x^2)+eps))) * weight ) ); RoPE (complex128 table `freqs`
- * [1024, head_dim/2] as (re,im) doubles) is skipped when freqs == NULL and for rows >= F*Hh*Ww.
+ * [1024, head_dim/2] as (re,im) doubles) is skipped when freqs == NULL and for tokens >= F*Hh*Ww. Row i is token
+ * row0 + i of the sequence (row0 > 0 for a sequence-parallel shard, distributed/sequence_parallel.py:47-56).
  * Replaces WanRMSNorm (model.py:82-85) + rope_apply (model.py:38-66) + the bf16 cast of attention.py:59-83. */
 int uv_rmsnorm_rope(const void* x, long ldx, void* out, long ldo, const float* weight, int L, int C, int head_dim,
-                    float eps, const double* freqs, int F, int Hh, int Ww, void* stream);
+                    float eps, const double* freqs, int F, int Hh, int Ww, int row0, void* stream);
 
 /* latent [Cin,F,H,W] f32 -> im2col rows [L, Kpad] bf16, column order (c,kt,kh,kw) = Conv3d.weight.flatten(1)
  * (model.py:378-379, 448-451). */

@@ -60,3 +60,55 @@ def test_two_rank_sharding_and_gather(n_samples):
 def test_seed_depends_on_global_index_only():
     assert parallel.sample_seed(42, 5) == 47
     assert [parallel.sample_seed(42, i) for i in range(*parallel.shard_range(8, 3, 4))] == [48, 49]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Ulysses sequence parallelism: the three exchanges of distributed attention against plain slicing (world size 2 and 3,
+# gloo; the gloo transport is the all-gather emulation, the layout logic is the one the RCCL path uses)
+# ---------------------------------------------------------------------------------------------------------------
+def _sp_worker(rank, world, port, L, C, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from univid_amd.parallel import SeqParallel
+        par = SeqParallel()
+        g = torch.Generator().manual_seed(5)
+        full = torch.randn(L, C, generator=g).to(torch.bfloat16)           # the same "all tokens, all heads" tensor on every rank
+        r0, r1 = par.token_range(L)
+        cp = C // world
+        assert sum(par.counts(L)) == L and par.shard_len(L) % 8 == 0
+        # q / k: my tokens x all heads -> all tokens x my heads
+        out = torch.empty(L, cp, dtype=torch.bfloat16)
+        par.heads_to_tokens(full[r0:r1].contiguous(), L, out)
+        ok = torch.equal(out, full[:, rank * cp:(rank + 1) * cp])
+        # V^T: [C, my tokens] -> [C/p, all tokens] at a column offset
+        vt = torch.zeros(cp, L + 72, dtype=torch.bfloat16)
+        par.heads_to_tokens_T(full[r0:r1].t(), L, vt, col0=8)
+        ok &= torch.equal(vt[:, 8:8 + L], full[:, rank * cp:(rank + 1) * cp].t()) and bool((vt[:, :8] == 0).all())
+        # attention output: all tokens x my heads -> my tokens x all heads
+        back = torch.empty(r1 - r0, C, dtype=torch.bfloat16)
+        par.tokens_to_heads(full[:, rank * cp:(rank + 1) * cp].contiguous(), L, back)
+        ok &= torch.equal(back, full[r0:r1])
+        # head rows
+        rows = par.gather_rows(full[r0:r1].float().contiguous(), L)
+        ok &= torch.equal(rows, full.float())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,L", [(2, 64), (2, 50), (3, 40), (3, 10)])
+def test_sequence_parallel_exchanges(world, L):
+    """(3, 10): the last rank owns no tokens at all and must still take part in every exchange."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sp_worker, args=(r, world, port, L, 12 * world, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(ok for _, ok in res), res

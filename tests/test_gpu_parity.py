@@ -15,6 +15,7 @@ Tolerances (written here on purpose, see DESIGN.md "Parity"):
     "truth" run of the oracle not larger than 1.3x the oracle's own (measured: equal to 3 digits).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -816,3 +817,59 @@ def test_full_size_dit_stack_equals_sequential():
     assert both[0].shape == (48, 13, 44, 80) and torch.isfinite(both[0]).all() and torch.isfinite(both[1]).all()
     assert torch.equal(both[0], a) and torch.equal(both[1], b)
     assert not torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Ulysses sequence parallelism: two processes share THE one GPU of the test box and talk over gloo
+# (RCCL needs one device per rank), so the exchanges go through the host-memory emulation while every kernel is the HIP one.
+# The sharded forward must reproduce the plain forward bit for bit: GEMM rows, RMSNorm/RoPE rows and (query, head) attention
+# problems are the same arithmetic wherever they run.
+# ---------------------------------------------------------------------------------------------------------------
+def _sp_gpu_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden("dit_tiny")
+        cfg, sd, m = _tiny_model(g["seed"], num_heads=4)
+        gen = torch.Generator().manual_seed(5)
+        x2 = torch.randn(48, 4, 16, 16, generator=gen)
+        ctx2 = torch.randn(7, cfg["text_dim"], generator=gen)
+        Lt = 256
+        xa, xb = g["x"].to(DEV), x2.to(DEV)
+        ca, cb = g["ctx"].to(DEV), ctx2.to(DEV)
+        ta, tb = g["t_two"].to(DEV), torch.full((1, Lt), 321.0, device=DEV)
+        odd = torch.randn(48, 3, 10, 12, generator=gen).to(DEV)          # 90 tokens: not a multiple of 8 -> must refuse
+        with torch.no_grad():
+            plain = m([xa, xb], torch.cat([ta, tb]), [ca, cb], Lt)
+            m.enable_sequence_parallel()
+            assert m.sp.size == world
+            sharded = m([xa, xb], torch.cat([ta, tb]), [ca, cb], Lt)       # stacked pair, two timesteps in sample a
+            single = m([xb], tb, [cb], Lt)[0]
+            refused = False
+            try:
+                m([odd], torch.full((1, 90), 500.0, device=DEV), [cb], 90)
+            except NotImplementedError:
+                refused = True
+        ok = torch.equal(sharded[0], plain[0]) and torch.equal(sharded[1], plain[1]) and torch.equal(single, plain[1])
+        q.put((rank, bool(ok), refused, float((sharded[0] - plain[0]).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sequence_parallel_forward_is_bit_identical(world):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sp_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok and refused for _, ok, refused, _ in res), res

@@ -25,7 +25,7 @@ SIGNATURES = {
     "uv_gemm_f32_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _P],
     "uv_flash_attn_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "uv_layernorm_mod": [_P, _L, _P, _L, _I, _I, _F, _I, _P, _L, _I, _I, _P, _P, _P, _I, _I, _P],
-    "uv_rmsnorm_rope": [_P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _I, _I, _I, _P],
+    "uv_rmsnorm_rope": [_P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _I, _I, _I, _I, _P],
     "uv_patchify_bf16": [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "uv_unpatchify_f32": [_P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "uv_sinusoid_f32": [_P, _P, _I, _I, _P],
@@ -181,9 +181,9 @@ def layernorm_mod(x, out, L, C, eps, mode=0, tab=None, shift_off=0, scale_off=0,
     return out
 
 
-def rmsnorm_rope(x, out, weight, L, C, D, eps, freqs=None, grid=(0, 0, 0)):
+def rmsnorm_rope(x, out, weight, L, C, D, eps, freqs=None, grid=(0, 0, 0), row0=0):
     _chk(x, torch.bfloat16, "rmsnorm_rope.x")
     _chk(out, torch.bfloat16, "rmsnorm_rope.out")
     call("uv_rmsnorm_rope", ptr(x), x.stride(0), ptr(out), out.stride(0), ptr(weight), L, C, D, float(eps), ptr(freqs),
-         int(grid[0]), int(grid[1]), int(grid[2]), stream_ptr())
+         int(grid[0]), int(grid[1]), int(grid[2]), int(row0), stream_ptr())
     return out

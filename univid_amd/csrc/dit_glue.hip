@@ -170,6 +170,7 @@ struct RmsRopeArgs {
     int L, C, D;          // D = head_dim
     int F, Hh, Ww;        // token grid
     int nf, nh, nw;       // complex columns per axis
+    int row0;             // global token index of row 0 (sequence-parallel shards), RoPE positions only
     float eps;
 };
 
@@ -212,11 +213,12 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsRopeArgs p) {
                 for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
             }
         }
-        const bool do_rope = p.freqs != nullptr && row < p.F * p.Hh * p.Ww;
+        const int grow = row + p.row0;               // token index in the whole sequence
+        const bool do_rope = p.freqs != nullptr && grow < p.F * p.Hh * p.Ww;
         int pf = 0, ph = 0, pw = 0;
         if (do_rope) {
-            pw = row % p.Ww;
-            const int t = row / p.Ww;
+            pw = grow % p.Ww;
+            const int t = grow / p.Ww;
             ph = t % p.Hh;
             pf = t / p.Hh;
         }
@@ -272,17 +274,18 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsRopeArgs p) {
 }
 
 extern "C" int uv_rmsnorm_rope(const void* x, long ldx, void* out, long ldo, const float* weight, int L, int C,
-                               int head_dim, float eps, const double* freqs, int F, int Hh, int Ww,
+                               int head_dim, float eps, const double* freqs, int F, int Hh, int Ww, int row0,
                                void* stream) {
     UV_CHECK_ARG(x && out && weight && L > 0, "uv_rmsnorm_rope: null pointer / empty");
     UV_CHECK_ARG(C % 8 == 0 && C <= 8192, "uv_rmsnorm_rope: C=%d must be a multiple of 8 and <= 8192", C);
     UV_CHECK_ARG(head_dim % 8 == 0 && C % head_dim == 0, "uv_rmsnorm_rope: bad head_dim %d", head_dim);
     UV_CHECK_ARG(ldx % 8 == 0 && ldo % 8 == 0, "uv_rmsnorm_rope: ldx/ldo must be multiples of 8");
+    UV_CHECK_ARG(row0 >= 0, "uv_rmsnorm_rope: negative row offset");
     if (freqs) UV_CHECK_ARG(F > 0 && Hh > 0 && Ww > 0 && F <= 1024 && Hh <= 1024 && Ww <= 1024,
                             "uv_rmsnorm_rope: grid (%d,%d,%d) outside the 1024-row RoPE table", F, Hh, Ww);
     RmsRopeArgs a;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.out = (bf16_t*)out; a.ldo = ldo; a.weight = weight; a.freqs = freqs;
-    a.L = L; a.C = C; a.D = head_dim; a.F = F; a.Hh = Hh; a.Ww = Ww; a.eps = eps;
+    a.L = L; a.C = C; a.D = head_dim; a.F = F; a.Hh = Hh; a.Ww = Ww; a.eps = eps; a.row0 = row0;
     const int c = head_dim / 2;  // model.py:43  split [c - 2*(c//3), c//3, c//3]
     a.nh = c / 3; a.nw = c / 3; a.nf = c - 2 * (c / 3);
     const int rpw = L >= 4096 ? 4 : 1;

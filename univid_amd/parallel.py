@@ -65,3 +65,127 @@ def denoise_batch(pipe, noises: Sequence[torch.Tensor], contexts, contexts_null,
     lo, hi = shard_range(n, rank, ws)
     local = [pipe.denoise(noises[i], contexts[i], contexts_null[i], sampling_steps, shift, guide_scale) for i in range(lo, hi)]
     return gather_latents(local, n) if gather else local
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Ulysses sequence parallelism: ONE sample's tokens sharded over the ranks of a group.
+#
+# Reference: models/wan/distributed/sequence_parallel.py:64-176 (sp_dit_forward / sp_attn_forward) and ulysses.py:9-47
+# (distributed_attention = all_to_all(q,k,v: scatter heads, gather tokens) -> flash_attention -> all_to_all back).
+# Here every row-wise kernel (LayerNorm, the projections, RMSNorm + RoPE with a global row offset, cross-attention, FFN)
+# runs on the rank's contiguous token range [r0, r1); only self-attention needs the other ranks' tokens, and gets them by
+# four all-to-alls per block and sample: q and k as [tokens, heads/p], V already TRANSPOSED as [heads/p * D, tokens] (the
+# layout the attention kernel reads), the attention output back as [tokens/p, heads]. On MI355X these are RCCL
+# all-to-alls over xGMI (backend "nccl"): 8.8 MB per rank and tensor at L = 11 440, p = 8. The gloo backend has no
+# all-to-all, so the CPU tests (and the two-processes-on-one-GPU parity test) emulate it with an all-gather through host
+# memory - a test transport, not a compute fallback: all arithmetic stays in the HIP kernels.
+# ---------------------------------------------------------------------------------------------------------------
+class SeqParallel:
+    def __init__(self, group=None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("sequence parallelism needs an initialised torch.distributed process group")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+
+    # ---- token partition: equal shards of ceil(L/p) rounded up to 8 tokens (16-byte V^T column alignment); the last
+    # ranks may own fewer tokens (or none for very short sequences)
+    def shard_len(self, L: int) -> int:
+        per = (L + self.size - 1) // self.size
+        return (per + 7) // 8 * 8
+
+    def token_range(self, L: int, rank: int = None):
+        rank = self.rank if rank is None else rank
+        ls = self.shard_len(L)
+        r0 = min(rank * ls, L)
+        return r0, min(r0 + ls, L)
+
+    def counts(self, L: int):
+        return [self.token_range(L, r)[1] - self.token_range(L, r)[0] for r in range(self.size)]
+
+    # ---- transport
+    def _all_to_all(self, recv, send):
+        """recv[s] <- send[rank] of rank s. All tensors contiguous; sizes are known to every rank by construction."""
+        if self.size == 1:
+            recv[0].copy_(send[0])
+            return
+        if self.backend == "nccl":
+            dist.all_to_all(recv, send, group=self.group)
+            return
+        # gloo (tests): all-gather of every rank's concatenated send chunks through host memory, then pick the own column
+        nbytes = [t.numel() * t.element_size() for t in send]
+        total = torch.tensor([sum(nbytes)], dtype=torch.int64)
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(self.size)]
+        dist.all_gather(sizes, total, group=self.group)
+        cap = int(max(int(s) for s in sizes))
+        flat = torch.zeros(cap, dtype=torch.uint8)
+        off = 0
+        for t, n in zip(send, nbytes):
+            flat[off:off + n] = t.detach().reshape(-1).view(torch.uint8).cpu() if n else flat[off:off]
+            off += n
+        gathered = [torch.empty(cap, dtype=torch.uint8) for _ in range(self.size)]
+        dist.all_gather(gathered, flat, group=self.group)
+        # chunk (src -> me) starts after src's chunks for ranks < me; their byte sizes follow from the receive shapes:
+        # what src sends to rank d has the same per-source geometry as what I receive, scaled by d's share - so every rank
+        # also publishes its chunk offsets
+        offs = torch.tensor([sum(nbytes[:d]) for d in range(self.size)], dtype=torch.int64)
+        all_offs = [torch.empty(self.size, dtype=torch.int64) for _ in range(self.size)]
+        dist.all_gather(all_offs, offs, group=self.group)
+        for s in range(self.size):
+            n = recv[s].numel() * recv[s].element_size()
+            o = int(all_offs[s][self.rank])
+            if n:
+                recv[s].copy_(gathered[s][o:o + n].view(recv[s].dtype).view(recv[s].shape).to(recv[s].device))
+
+    # ---- the three exchanges of distributed attention
+    def heads_to_tokens(self, x_loc: torch.Tensor, L: int, out: torch.Tensor):
+        """x_loc [n_me, C] (my tokens, all heads) -> out [L, C/p] (all tokens, my heads). q and k."""
+        p, cp = self.size, x_loc.shape[1] // self.size
+        n_me = x_loc.shape[0]
+        packed = x_loc.view(n_me, p, cp).transpose(0, 1).contiguous()            # [p, n_me, cp]
+        send = [packed[d] for d in range(p)]
+        recv = [out[self.token_range(L, s)[0]:self.token_range(L, s)[1]] for s in range(p)]
+        self._all_to_all(recv, send)
+        return out
+
+    def heads_to_tokens_T(self, xt_loc: torch.Tensor, L: int, out_t: torch.Tensor, col0: int = 0):
+        """xt_loc [C, n_me] (V^T of my tokens, any column stride) -> out_t[:, col0 : col0 + L] = V^T of all tokens for my
+        heads ([C/p, ...])."""
+        p, cp = self.size, xt_loc.shape[0] // self.size
+        n_me = xt_loc.shape[1]
+        send = [xt_loc[d * cp:(d + 1) * cp].contiguous() for d in range(p)]      # [cp, n_me] each
+        cnt = self.counts(L)
+        recv = [torch.empty(cp, cnt[s], dtype=xt_loc.dtype, device=xt_loc.device) for s in range(p)]
+        self._all_to_all(recv, send)
+        for s in range(p):
+            r0, r1 = self.token_range(L, s)
+            out_t[:, col0 + r0:col0 + r1] = recv[s]
+        return out_t
+
+    def tokens_to_heads(self, y_full: torch.Tensor, L: int, out_loc: torch.Tensor):
+        """y_full [L, C/p] (all tokens, my heads) -> out_loc [n_me, C] (my tokens, all heads). Attention output."""
+        p, cp = self.size, y_full.shape[1]
+        n_me = out_loc.shape[0]
+        send = [y_full[self.token_range(L, d)[0]:self.token_range(L, d)[1]] for d in range(p)]
+        recv_buf = torch.empty(p, n_me, cp, dtype=y_full.dtype, device=y_full.device)
+        self._all_to_all([recv_buf[s] for s in range(p)], send)
+        out_loc.view(n_me, p, cp).copy_(recv_buf.transpose(0, 1))
+        return out_loc
+
+    def gather_rows(self, y_loc: torch.Tensor, L: int) -> torch.Tensor:
+        """y_loc [n_me, K] -> [L, K] on every rank (head output before unpatchify; gather_forward, util.py:43-51)."""
+        if self.size == 1:
+            return y_loc
+        ls = self.shard_len(L)
+        buf = torch.zeros(ls, y_loc.shape[1], dtype=y_loc.dtype, device=y_loc.device)
+        buf[:y_loc.shape[0]] = y_loc
+        if self.backend == "nccl":
+            parts = [torch.empty_like(buf) for _ in range(self.size)]
+            dist.all_gather(parts, buf, group=self.group)
+        else:
+            host = [torch.empty(buf.shape, dtype=buf.dtype) for _ in range(self.size)]
+            dist.all_gather(host, buf.cpu(), group=self.group)
+            parts = [h.to(y_loc.device) for h in host]
+        cnt = self.counts(L)
+        return torch.cat([parts[s][:cnt[s]] for s in range(self.size)], 0)

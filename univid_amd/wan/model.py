@@ -87,9 +87,11 @@ class WanSelfAttention(nn.Module):
     def prepare(self):
         self._prep = {n: _Prepared(getattr(self, n)) for n in ("q", "k", "v", "o")}
 
-    def _self_attn(self, h, L, grid, freqs, x_resid, gate, gate_tid, batch=1):
+    def _self_attn(self, h, L, grid, freqs, x_resid, gate, gate_tid, batch=1, sp=None):
         """h: bf16 [batch*L, C] modulated input (samples stacked along the token axis). Adds o(attn) * gate into x_resid
-        (fp32) in the GEMM epilogue."""
+        (fp32) in the GEMM epilogue. sp = (SeqParallel, L_total, r0): h holds this rank's token range of every sample."""
+        if sp is not None:
+            return self._self_attn_sp(h, L, grid, freqs, x_resid, gate, gate_tid, batch, sp)
         C, H, D = self.dim, self.num_heads, self.head_dim
         p = self._prep
         dev = h.device
@@ -107,6 +109,45 @@ class WanSelfAttention(nn.Module):
         att = torch.empty(M, C, dtype=BF16, device=dev)
         _lib.flash_attn(ql, kl, vt, att, L, L, H, D, 1.0 / math.sqrt(D), batch=batch)
         _lib.gemm_bf16(att, p["o"].w, p["o"].b, x_resid, EPI_GATE_RESID_F32, M=M, gate=gate, gate_tid=gate_tid)
+
+    def _self_attn_sp(self, h, n, grid, freqs, x_resid, gate, gate_tid, batch, sp):
+        """Ulysses form (distributed/sequence_parallel.py:147-176, ulysses.py:9-47): projections, RMSNorm and RoPE on the
+        rank's n tokens of each sample; q/k/V^T exchanged to [all tokens, heads/p]; attention over the whole sequence for
+        the rank's heads; output exchanged back; o-projection + gated residual on the rank's tokens."""
+        par, Lt, r0 = sp
+        C, H, D = self.dim, self.num_heads, self.head_dim
+        P = par.size
+        if H % P or Lt % 8:
+            raise NotImplementedError(f"sequence parallel needs heads % ranks == 0 and tokens % 8 == 0 (H={H}, p={P}, L={Lt})")
+        p = self._prep
+        dev = h.device
+        M = batch * n
+        Cp, Hp = C // P, H // P
+        ql = torch.empty(M, C, dtype=BF16, device=dev)
+        kl = torch.empty(M, C, dtype=BF16, device=dev)
+        vt = torch.zeros(C, _round_up(max(M, 1), 64), dtype=BF16, device=dev)
+        qf = torch.empty(batch * Lt, Cp, dtype=BF16, device=dev)
+        kf = torch.empty(batch * Lt, Cp, dtype=BF16, device=dev)
+        vtf = _vt_scratch("vt_sp", Cp, batch, Lt, dev)
+        if M:
+            _lib.gemm_bf16(h, p["q"].w, p["q"].b, ql, EPI_BF16, M=M)
+            _lib.gemm_bf16(h, p["k"].w, p["k"].b, kl, EPI_BF16, M=M)
+            _lib.gemm_bf16(h, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=M)
+        for b in range(batch):
+            rows = slice(b * n, (b + 1) * n)
+            if n:
+                _lib.rmsnorm_rope(ql[rows], ql[rows], self.norm_q.weight, n, C, D, self.eps, freqs, grid, row0=r0)
+                _lib.rmsnorm_rope(kl[rows], kl[rows], self.norm_k.weight, n, C, D, self.eps, freqs, grid, row0=r0)
+            par.heads_to_tokens(ql[rows], Lt, qf[b * Lt:(b + 1) * Lt])
+            par.heads_to_tokens(kl[rows], Lt, kf[b * Lt:(b + 1) * Lt])
+            par.heads_to_tokens_T(vt[:, b * n:(b + 1) * n], Lt, vtf, col0=b * Lt)
+        attf = torch.empty(batch * Lt, Cp, dtype=BF16, device=dev)
+        _lib.flash_attn(qf, kf, vtf, attf, Lt, Lt, Hp, D, 1.0 / math.sqrt(D), batch=batch)
+        att = torch.empty(M, C, dtype=BF16, device=dev)
+        for b in range(batch):
+            par.tokens_to_heads(attf[b * Lt:(b + 1) * Lt], Lt, att[b * n:(b + 1) * n])
+        if M:
+            _lib.gemm_bf16(att, p["o"].w, p["o"].b, x_resid, EPI_GATE_RESID_F32, M=M, gate=gate, gate_tid=gate_tid)
 
     def forward(self, x, seq_lens, grid_sizes, freqs):
         """Reference signature (model.py:126-155): x [B, L, C] -> [B, L, C] bf16. Keys >= seq_lens[b] are masked,
@@ -199,7 +240,7 @@ class WanAttentionBlock(nn.Module):
         self.cross_attn.prepare()
         self._prep = {"ffn0": _Prepared(self.ffn[0]), "ffn2": _Prepared(self.ffn[2])}
 
-    def _run(self, x, L, e0_rows, tid, grid, freqs, ctx, first_block, batch=1):
+    def _run(self, x, L, e0_rows, tid, grid, freqs, ctx, first_block, batch=1, sp=None):
         """x: fp32 [batch*L, C] residual stream (independent samples stacked along the token axis), updated IN PLACE.
         e0_rows: fp32 [n_t, 6C]; tid int32 [batch*L] | None; ctx: bf16 [batch*Lc, C] embedded context(s)."""
         C = self.dim
@@ -213,7 +254,7 @@ class WanAttentionBlock(nn.Module):
         # self-attention (model.py:243-247)
         _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=0, scale_off=C, tid=tid,
                            round_ln=first_block)
-        self.self_attn._self_attn(h, Ls, grid, freqs, x, tab[:, 2 * C:], tid, batch)
+        self.self_attn._self_attn(h, Ls, grid, freqs, x, tab[:, 2 * C:], tid, batch, sp)
         # cross-attention (model.py:251)
         if self.cross_attn_norm:
             _lib.layernorm_mod(x, h, L, C, self.eps, mode=2, w=self.norm3.weight, b=self.norm3.bias)
@@ -353,6 +394,7 @@ class WanModel(nn.Module):
             self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
                                     rope_params(1024, 2 * (d // 6))], dim=1)
         self._prep = None
+        self.sp = None   # SeqParallel when Ulysses sequence parallelism is enabled (enable_sequence_parallel)
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
 
     # ---- weight preparation -------------------------------------------------------------------------------
@@ -463,24 +505,48 @@ class WanModel(nn.Module):
             a = torch.empty(B * L, Kp, dtype=BF16, device=dev)
             for j, i in enumerate(idx):
                 _lib.call("uv_patchify_bf16", _lib.ptr(xs_in[i]), _lib.ptr(a[j * L:]), a.stride(0), cin, F, H, W, pt, ph, pw, Kp, sp())
-            xs = torch.empty(B * L, C, dtype=torch.float32, device=dev)
-            _lib.gemm_bf16(a, self._prep["patch"].w, self._prep["patch"].b, xs, EPI_F32_FROM_BF16)
             # timesteps: distinct values -> rows; token -> row map (padding tokens beyond L are never computed)
             tb = torch.cat([t[i].to(device=dev, dtype=torch.float32).flatten()[:L] for i in idx])
             tvals, inv = torch.unique(tb, return_inverse=True)
             tid = None if tvals.numel() == 1 else inv.to(torch.int32).contiguous()
             e_rows, e0_rows = self._time_rows(tvals.contiguous())
             ctx = ctx_all[idx[0]] if B == 1 else torch.cat([ctx_all[i] for i in idx], 0)
+            par = self.sp if (self.sp is not None and self.sp.size > 1) else None
+            if par is None:
+                n, sp_arg = L, None
+            else:
+                # sequence parallel (distributed/sequence_parallel.py:116-119): this rank keeps tokens [r0, r1) of every sample
+                r0, r1 = par.token_range(L)
+                n, sp_arg = r1 - r0, (par, L, r0)
+                a = torch.cat([a[j * L + r0:j * L + r1] for j in range(B)], 0)
+                if tid is not None:
+                    tid = torch.cat([tid[j * L + r0:j * L + r1] for j in range(B)], 0).contiguous()
+            xs = torch.empty(B * n, C, dtype=torch.float32, device=dev)
+            if B * n:
+                _lib.gemm_bf16(a, self._prep["patch"].w, self._prep["patch"].b, xs, EPI_F32_FROM_BF16)
             for li, blk in enumerate(self.blocks):
-                blk._run(xs, L, e0_rows, tid, (Fp, Hp, Wp), fr, ctx, first_block=(li == 0), batch=B)
-            yh = self.head._run(xs, B * L, e_rows, tid)
+                if par is None or n:
+                    blk._run(xs, n, e0_rows, tid, (Fp, Hp, Wp), fr, ctx, first_block=(li == 0), batch=B, sp=sp_arg)
+                else:   # a rank without tokens still takes part in the self-attention exchanges
+                    blk.self_attn._self_attn_sp(xs.new_empty(0, C).to(BF16), 0, (Fp, Hp, Wp), fr, xs, None, None, B, sp_arg)
+            yh = self.head._run(xs, B * n, e_rows, tid) if B * n else xs.new_empty(0, self.head.head.out_features)
             for j, i in enumerate(idx):
                 out = torch.empty(self.out_dim, Fp * pt, Hp * ph, Wp * pw, dtype=torch.float32, device=dev)
-                yj = yh[j * L:(j + 1) * L]
+                yj = yh[j * n:(j + 1) * n]
+                if par is not None:
+                    yj = par.gather_rows(yj, L).contiguous()     # gather_forward (sequence_parallel.py:139)
                 _lib.call("uv_unpatchify_f32", _lib.ptr(yj), yj.stride(0), _lib.ptr(out), self.out_dim, Fp, Hp, Wp, pt, ph, pw,
                           sp())
                 outs[i] = out
         return outs
+
+    def enable_sequence_parallel(self, group=None):
+        """Ulysses sequence parallelism over the ranks of `group` (what the reference's `use_sp=True` installs,
+        textimage2video.py:106-118): every rank calls forward with the SAME inputs and gets the full outputs; tokens are
+        sharded inside (univid_amd/parallel.py: SeqParallel). Pass group=False to switch it off."""
+        from ..parallel import SeqParallel
+        self.sp = None if group is False else SeqParallel(group)
+        return self
 
     def unpatchify(self, x, grid_sizes):
         """model.py:499-522, for callers that use it directly."""

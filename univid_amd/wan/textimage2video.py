@@ -81,9 +81,9 @@ class WanTI2V:
     def __init__(self, config=TI2VConfig, checkpoint_dir=None, device_id=0, rank=0, t5_fsdp=False, dit_fsdp=False,
                  use_sp=False, t5_cpu=False, init_on_cpu=True, convert_model_dtype=False, *, model: WanModel = None,
                  vae=None, text_encoder: Optional[Callable] = None, device=None):
-        if t5_fsdp or dit_fsdp or use_sp:
-            raise NotImplementedError("FSDP / Ulysses SP are not part of this build (UniVid passes False for all three, "
-                                      "models/model_pipeline.py:2205-2207)")
+        if t5_fsdp or dit_fsdp:
+            raise NotImplementedError("FSDP is not part of this build (UniVid passes False, models/model_pipeline.py:2205-2207; "
+                                      "the fp32 masters + bf16 operands of the 5B DiT are 30 GB of a 288 GB GPU)")
         if convert_model_dtype:
             raise NotImplementedError("convert_model_dtype=True (bf16 parameters) is not UniVid's setting")
         self.device = torch.device(device) if device is not None else torch.device(f"cuda:{device_id}")
@@ -105,6 +105,11 @@ class WanTI2V:
             from .checkpoint import load_wan_model
             model = load_wan_model(checkpoint_dir)
         self.model = model.eval().requires_grad_(False).to(self.device)
+        if use_sp:
+            # textimage2video.py:106-118: Ulysses sequence parallelism over all ranks of the default process group; every rank
+            # runs the same sample (same seed) and holds the full result after each forward
+            self.model.enable_sequence_parallel()
+            self.sp_size = self.model.sp.size
 
     # ---- prompt embeds ---------------------------------------------------------------------------------------
     def _encode(self, prompt, embeds):
