@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer DiT blocks (result is NOT the metric)")
     ap.add_argument("--kernel-times", action="store_true", help="HIP-event timing of every kernel class (adds ~1%% overhead)")
+    ap.add_argument("--sp", action="store_true", help="N > 1: Ulysses sequence parallelism (ONE sample's tokens sharded over the "
+                    "ranks, strong scaling) instead of the default one-sample-per-GPU replicas")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -155,7 +157,10 @@ def main():
     _lib.init()
     model = build_model(cfg, device, seed=0)
 
-    g = torch.Generator(device=device).manual_seed(42 + rank)
+    use_sp = bool(args.sp and world > 1)
+    if use_sp:
+        model.enable_sequence_parallel()
+    g = torch.Generator(device=device).manual_seed(42 + (0 if use_sp else rank))   # SP: every rank holds the same sample
     latent = torch.randn(*LATENT, device=device, generator=g)
     ctx = [torch.randn(77, cfg["text_dim"], device=device, generator=g) * 0.1]
     ctx_null = [torch.randn(12, cfg["text_dim"], device=device, generator=g) * 0.1]
@@ -187,7 +192,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
             latent = one_step(i, latent)
-        if world > 1:  # the single collective of the path: final latents to every rank (8.8 MB/GPU)
+        if world > 1 and not use_sp:  # the single collective of the path: final latents to every rank (8.8 MB/GPU)
             gathered = [torch.empty_like(latent) for _ in range(world)]
             dist.all_gather(gathered, latent)
         barrier()
@@ -229,12 +234,12 @@ def main():
                         "flops_per_launch": launch_flops}
         step_flops = 2 * dit_forward_flops(L_TOKENS, cfg)
         out = {
-            "metric": "denoise_steps_per_sec", "value": round(world * args.steps / dt_max, 4), "unit": "steps/s",
+            "metric": "denoise_steps_per_sec", "value": round((1 if use_sp else world) * args.steps / dt_max, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if use_sp else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "49-frame 704x1280 latent [48,13,44,80], L=11440 tokens; TI2V-5B DiT (dim 3072, ffn 14336, "
                                    "24 heads, %d layers); 1 step = cond+uncond forward + CFG + UniPC; one sample per GPU" % cfg["num_layers"],
-                       "samples_per_gpu": 1, "guide_scale": GUIDE, "shift": SHIFT, "parallelism": f"replicas x{world}, all-gather of final latents"},
+                       "samples_per_gpu": 1, "guide_scale": GUIDE, "shift": SHIFT, "parallelism": (f"ulysses sequence parallel x{world}, 4 all-to-alls per block" if use_sp else f"replicas x{world}, all-gather of final latents")},
             "step_tflop": round(step_flops / 1e12, 1),
             "model_tflops_per_gpu": round(step_flops * args.steps / dt_max / 1e12, 1),
             "mfma_frac_whole_step": round(step_flops * args.steps / dt_max / 1e12 / PEAK_BF16_TFLOPS, 4),

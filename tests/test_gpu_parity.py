@@ -873,3 +873,50 @@ def test_sequence_parallel_forward_is_bit_identical(world):
     for p in procs:
         p.join(60)
     assert all(ok and refused for _, ok, refused, _ in res), res
+
+
+def _sp_full_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from univid_amd.wan.model import WanModel
+        from univid_amd.wan.textimage2video import TI2VConfig
+        cfg = dict(TI2VConfig.dit, num_layers=1)
+        with torch.device(DEV):
+            m = WanModel.from_config(cfg)
+        m = m.eval().requires_grad_(False)
+        m.init_weights(5)
+        m.prepare()
+        g = torch.Generator(device=DEV).manual_seed(4)
+        lat = torch.randn(48, 13, 44, 80, device=DEV, generator=g)
+        ca = torch.randn(77, cfg["text_dim"], device=DEV, generator=g) * 0.1
+        cb = torch.randn(12, cfg["text_dim"], device=DEV, generator=g) * 0.1
+        Ltok = 13 * 22 * 40
+        tv = torch.full((1, Ltok), 431.0, device=DEV)
+        with torch.no_grad():
+            plain = m([lat, lat], t=torch.cat([tv, tv]), context=[ca, cb], seq_len=Ltok)
+            m.enable_sequence_parallel()
+            sharded = m([lat, lat], t=torch.cat([tv, tv]), context=[ca, cb], seq_len=Ltok)
+        q.put((rank, bool(torch.equal(sharded[0], plain[0]) and torch.equal(sharded[1], plain[1]))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_full_size_sequence_parallel_bit_identical():
+    """The bench shape (11 440 tokens, 24 heads x 128, cond+uncond stacked), one TI2V-5B-width block, 2 ranks: token shards of
+    5 720, 12 heads per rank in the exchanged attention; bit-identical to the unsharded forward."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sp_full_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res
