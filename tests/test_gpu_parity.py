@@ -920,3 +920,34 @@ def test_full_size_sequence_parallel_bit_identical():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+def test_full_size_t2v_and_i2v_end_to_end():
+    """The whole product path at the bench size with the production model sizes (30-block TI2V-5B DiT, full-width VAE, random-init
+    weights): WanTI2V.t2v for 2 sampler steps + VAE decode of the 49-frame 704x1280 clip, and an i2v start from its first frame
+    (VAE encode of one image + masked denoising). Shapes, value range, determinism (same seed -> same bits)."""
+    from univid_amd.wan.model import WanModel
+    from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    with torch.device(DEV):
+        m = WanModel.from_config(TI2VConfig.dit)
+    m = m.eval().requires_grad_(False)
+    m.init_weights(0)
+    m.prepare()
+    vae = Wan2_2_VAE(device=DEV, seed=0)
+    pipe = WanTI2V(model=m, vae=vae, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    pe = [torch.randn(40, 4096, device=DEV, generator=g) * 0.1]
+    ne = [torch.randn(9, 4096, device=DEV, generator=g) * 0.1]
+    with torch.no_grad():
+        v1 = pipe.t2v("", size=(1280, 704), frame_num=49, sampling_steps=2, seed=7, prompt_embeds=pe, negative_prompt_embeds=ne)
+        lat2 = pipe.t2v("", size=(1280, 704), frame_num=49, sampling_steps=2, seed=7, prompt_embeds=pe, negative_prompt_embeds=ne,
+                        decode=False)
+        lat3 = pipe.t2v("", size=(1280, 704), frame_num=49, sampling_steps=2, seed=7, prompt_embeds=pe, negative_prompt_embeds=ne,
+                        decode=False)
+        img = v1[:, 0].clamp(-1, 1).contiguous()
+        li = pipe.i2v("", img, max_area=704 * 1280, frame_num=49, sampling_steps=2, seed=3, prompt_embeds=pe,
+                      negative_prompt_embeds=ne, decode=False)
+    assert v1.shape == (3, 49, 704, 1280) and torch.isfinite(v1).all() and v1.abs().max() <= 1.0
+    assert lat2.shape == (48, 13, 44, 80) and torch.equal(lat2, lat3)
+    assert li.shape == (48, 13, 44, 80) and torch.isfinite(li).all()
