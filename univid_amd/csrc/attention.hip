@@ -6,7 +6,7 @@
 //           q/k/v cast to bf16 :59-83, result cast back :130), called from
 //           WanSelfAttention.forward model.py:145-150 and WanCrossAttention.forward model.py:175.
 //
-// Structure (one workgroup = 8 waves = 256 queries of one head; KV tile = 64 keys):
+// Structure (default: one workgroup = 4 waves = 128 queries of one head, two workgroups per CU; KV tile = 64 keys):
 //   * swapped product S^T = K.Q^T with v_mfma_f32_32x32x16_bf16: the query sits on the lane, its
 //     32 keys of a tile sit in the 16 accumulator registers of both half-waves, so the softmax row
 //     max / sum are register-local plus ONE exchange with lane^32.
@@ -20,6 +20,11 @@
 //     chunk ^= (row>>1)&7: both make the ds_read_b128 fragment reads bank-conflict-free.
 //   * LDS-DMA double buffer: tile t+1 is streamed straight into the other LDS buffer (global_load_lds) while tile t
 //     is computed; one vmcnt(0) + one barrier per tile.
+//   * the softmax reference maximum moves only when a row maximum outgrows it by more than 2^UV_ATT_DEFER.
+//   * independent samples are one launch: q/k/out rows and V^T COLUMNS stacked per sample.
+// Template parameters: D head_dim (128 / 64), NW waves per workgroup, STAMP in-kernel cycle stamps (diagnostic entry
+// uvdbg_flash_attn_stamps), QB = 2 the experimental one-wave-per-SIMD 64-queries-per-wave form (UV_ATTN_QB=2, see DESIGN
+// section 9), SGB fragment reads scheduled 6 ahead of their MFMA.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>

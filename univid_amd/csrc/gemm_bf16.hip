@@ -14,6 +14,14 @@
 // the 16x16x32 fragment reads bank-conflict-free on 128-byte rows.
 // The MFMA is issued as D = Wfrag x Afrag so that a lane ends up with 4 CONSECUTIVE n for one m:
 // epilogue stores are 8 B (bf16) / 16 B (fp32) per lane instead of 2 B scatters.
+//
+// Kernels in this file:
+//   gemm_bf16_8ph_kernel  256x256 tiles, 8 waves in two ping-pong groups, LDS-DMA in flight across raw barriers: every
+//                         large projection (tile_cfg 7; what tile_cfg 0 picks for M >= 2048, N % 256 == 0, K % 128 == 0)
+//   gemm_bf16_nt_kernel   generic BM x BN tile, NS LDS stages: 128x128 / 8 waves / 4-stage ring for leftover-row strips
+//                         and small-M projections (tile_cfg 12), 2-stage 4-wave and 16-wave forms for everything else
+//   uv_gemm_bf16_nt       shape-based choice, leftover-row split (launch_m_split)
+//   uvdbg_gemm_stamps     diagnostic build with in-kernel cycle stamps (tools/gemm_stamps.py), not part of the ABI
 #include "common.h"
 
 #define UV_BK 64  // k elements per LDS tile (128-byte rows)
