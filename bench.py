@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer DiT blocks (result is NOT the metric)")
     ap.add_argument("--kernel-times", action="store_true", help="HIP-event timing of every kernel class (adds ~1%% overhead)")
+    ap.add_argument("--shape", choices=["A", "B"], default="A", help="A (default, the metric): 49-frame 704x1280 latent [48,13,44,80], "
+                    "L = 11 440. B: the literal '49x90x160 latent' stress shape of BASELINE.json's target, [48,49,90,160], L = 176 400 "
+                    "(26 PFLOP per step: use --steps 1 --warmup 1; not the metric)")
     ap.add_argument("--sp", action="store_true", help="N > 1: Ulysses sequence parallelism (ONE sample's tokens sharded over the "
                     "ranks, strong scaling) instead of the default one-sample-per-GPU replicas")
     args = ap.parse_args()
@@ -147,6 +150,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
+    global LATENT, L_TOKENS
+    if args.shape == "B":
+        LATENT, L_TOKENS = (48, 49, 90, 160), 49 * 45 * 80
     from univid_amd.wan.textimage2video import TI2VConfig   # configs/wan_ti2v_5B.py:17-29
     from univid_amd import _lib
     from univid_amd.wan.fm_solvers_unipc import FlowUniPCMultistepScheduler
@@ -227,7 +233,9 @@ def main():
                 traffic *= prof["uv_flash_attn_bf16"][0][2] / self_attn_flops(L_TOKENS, cfg["dim"])   # samples per launch
             except Exception:
                 pass
-            roofline = {"kernel": "flash_attn_fwd_kernel<128> (self-attention, cond+uncond batch 2 x Lq=Lk=11440, 24 heads)", "bound": "mfma",
+            if args.shape != "A":
+                traffic = None    # the PMC passes were taken at shape A
+            roofline = {"kernel": f"flash_attn_fwd_kernel<128> (self-attention, cond+uncond batch 2 x Lq=Lk={L_TOKENS}, 24 heads)", "bound": "mfma",
                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(self_ev),
@@ -237,8 +245,10 @@ def main():
             "metric": "denoise_steps_per_sec", "value": round((1 if use_sp else world) * args.steps / dt_max, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong" if use_sp else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "49-frame 704x1280 latent [48,13,44,80], L=11440 tokens; TI2V-5B DiT (dim 3072, ffn 14336, "
-                                   "24 heads, %d layers); 1 step = cond+uncond forward + CFG + UniPC; one sample per GPU" % cfg["num_layers"],
+            "config": {"workload": ("49-frame 704x1280 latent [48,13,44,80], L=11440 tokens" if args.shape == "A" else
+                                    "STRESS SHAPE (not the metric): literal 49x90x160 latent [48,49,90,160], L=176400 tokens") +
+                                   "; TI2V-5B DiT (dim 3072, ffn 14336, 24 heads, %d layers); 1 step = cond+uncond forward + CFG + UniPC; "
+                                   "one sample per GPU" % cfg["num_layers"],
                        "samples_per_gpu": 1, "guide_scale": GUIDE, "shift": SHIFT, "parallelism": (f"ulysses sequence parallel x{world}, 4 all-to-alls per block" if use_sp else f"replicas x{world}, all-gather of final latents")},
             "step_tflop": round(step_flops / 1e12, 1),
             "model_tflops_per_gpu": round(step_flops * args.steps / dt_max / 1e12, 1),
@@ -248,7 +258,7 @@ def main():
         }
         if args.kernel_times:
             out["kernel_times"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in ktimes.items()}
-        if world == 1 and not args.no_vae and not args.layers:
+        if world == 1 and not args.no_vae and not args.layers and args.shape == "A":
             out["vae_decode"] = vae_decode_metric(device, "bf16x3")
             out["vae_decode_fp32"] = vae_decode_metric(device, "fp32")
         if world == 1 and not args.no_cpu_baseline:
