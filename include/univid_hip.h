@@ -94,6 +94,10 @@ int uv_cast_f32_bf16(const float* in, void* out, long n, void* stream);
 /* x_f32 += float(y_bf16): un-fused residual used when WanCrossAttention.forward has been re-assigned (UniVid's hook). */
 int uv_add_bf16_resid(float* x, long ldx, const void* y, long ldy, int L, int C, void* stream);
 
+/* out[r] = x[r] / max(||x[r]||_2, eps): torch.nn.functional.normalize(dim=-1) of the SigLIP2 ranker's embeddings
+ * (models/BAGEL/eval_understanding.py:185,195). */
+int uv_l2_normalize_rows_f32(const float* x, long ldx, float* out, long ldo, int R, int C, float eps, void* stream);
+
 /* ---- sampler (CFG + flow UniPC order 2 / bh2 / predict-x0) -------------------------------------------------- */
 /* noise_pred = uncond + gs*(cond - uncond) (textimage2video.py:385); x0 = sample - sigma*noise_pred
  * (fm_solvers_unipc.py:323). noise_pred may be NULL. */

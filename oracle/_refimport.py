@@ -183,3 +183,16 @@ def ref_masks_like(tensor, zero=False):
     ns = {"torch": torch}
     exec(compile(ast.Module(body=[fn], type_ignores=[]), "utils.py:masks_like", "exec"), ns)
     return ns["masks_like"](tensor, zero=zero)
+
+
+def ref_mmr_select(embs, query_emb, K, lam=0.5):
+    """Executes mmr_select from models/BAGEL/eval_understanding.py:225-240 without importing the file's top-level dependencies
+    (decord, openai, PIL, ...): only that function's source is compiled."""
+    import ast
+    from typing import List
+    path = os.path.join(REF_ROOT, "models", "BAGEL", "eval_understanding.py")
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "mmr_select"][0]
+    ns = {"torch": torch, "List": List}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "eval_understanding.py:mmr_select", "exec"), ns)
+    return ns["mmr_select"](embs, query_emb, K, lam)

@@ -19,7 +19,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import _refimport, sampler, unipc, wan_dit, wan_vae  # noqa: E402
+from oracle import _refimport, sampler, siglip2, unipc, wan_dit, wan_vae  # noqa: E402
 from univid_amd import detinit  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -243,6 +243,54 @@ def gen_masks():
     save("masks_like", ones1=a1[0], ones2=a2[0], zero1=b1[0], zero2=b2[0])
 
 
+def gen_siglip2():
+    """BASELINE config 5. The towers' arithmetic is HF transformers' Siglip2Model (the reference only calls it,
+    eval_understanding.py:171-206): the oracle is pinned against transformers itself, with the same deterministic weights
+    loaded into both; mmr_select against the reference's own function."""
+    print("siglip2 (transformers %s)" % __import__("transformers").__version__)
+    from transformers import Siglip2Config, Siglip2Model
+    cfg = siglip2.TINY_CFG
+    seed = 3
+    hc = Siglip2Config(vision_config=dict(cfg["vision"], hidden_act="gelu_pytorch_tanh", attention_dropout=0.0),
+                       text_config=dict(cfg["text"], hidden_act="gelu_pytorch_tanh", attention_dropout=0.0))
+    m = Siglip2Model(hc).eval()
+    sd = siglip2.make_state_dict(cfg, seed)
+    inc = m.load_state_dict(sd, strict=False)
+    assert not inc.unexpected_keys and set(inc.missing_keys) <= {"logit_scale", "logit_bias"}
+    g = torch.Generator().manual_seed(11)
+    B, N, pdim = 6, cfg["vision"]["num_patches"], 3 * cfg["vision"]["patch_size"] ** 2
+    pv = torch.randn(B, N, pdim, generator=g)
+    shapes = torch.tensor([[8, 8], [8, 8], [8, 8], [6, 10], [4, 7], [5, 5]])
+    mask = torch.zeros(B, N, dtype=torch.int64)
+    for b, (h, w) in enumerate(shapes.tolist()):
+        mask[b, :h * w] = 1
+    ids = torch.randint(0, cfg["text"]["vocab_size"], (2, cfg["text"]["max_position_embeddings"]), generator=g)
+    am = torch.ones_like(ids)
+    am[1, 9:] = 0
+    with torch.no_grad():
+        fi = m.get_image_features(pixel_values=pv, pixel_attention_mask=mask, spatial_shapes=shapes)
+        fi = fi.pooler_output if hasattr(fi, "pooler_output") else fi
+        ft = m.get_text_features(input_ids=ids)
+        ft = ft.pooler_output if hasattr(ft, "pooler_output") else ft
+        ftm = m.get_text_features(input_ids=ids, attention_mask=am)
+        ftm = ftm.pooler_output if hasattr(ftm, "pooler_output") else ftm
+    oi, ot, otm = siglip2.image_features(sd, cfg, pv, mask, shapes), siglip2.text_features(sd, cfg, ids), siglip2.text_features(sd, cfg, ids, am)
+    for a, b_, n in ((fi, oi, "image"), (ft, ot, "text"), (ftm, otm, "text+mask")):
+        err = (a - b_).abs().max().item()
+        print(f"   oracle vs transformers {n}: max abs diff {err:.2e}")
+        assert err < 5e-6, n
+    v = torch.nn.functional.normalize(fi, dim=-1)
+    t = torch.nn.functional.normalize(ft[:1], dim=-1)
+    idx, vals = siglip2.rank_frames(fi, ft[:1], 4)
+    embs = torch.nn.functional.normalize(torch.randn(12, 16, generator=g), dim=-1)
+    qe = torch.nn.functional.normalize(torch.randn(1, 16, generator=g), dim=-1)
+    mm = [_refimport.ref_mmr_select(embs, qe, K, lam) for K, lam in ((5, 0.5), (12, 0.2), (20, 0.9))]
+    assert mm == [siglip2.mmr_select(embs, qe, K, lam) for K, lam in ((5, 0.5), (12, 0.2), (20, 0.9))]
+    save("siglip2_tiny", seed=seed, pixel_values=pv, spatial_shapes=shapes, pixel_attention_mask=mask, input_ids=ids, attention_mask=am,
+         image_features=fi, text_features=ft, text_features_masked=ftm, rank_idx=np.asarray(idx), rank_vals=np.asarray(vals),
+         mmr_embs=embs, mmr_query=qe, mmr_5_05=np.asarray(mm[0]), mmr_12_02=np.asarray(mm[1]), mmr_20_09=np.asarray(mm[2]))
+
+
 def main():
     assert _refimport.available(), "the reference is not mounted; fixtures can only be generated in the build container"
     os.makedirs(OUT, exist_ok=True)
@@ -250,7 +298,8 @@ def main():
     torch.set_num_threads(8)
     only = sys.argv[1:]
     gens = {"unipc": lambda: gen_unipc(ns), "masks": gen_masks, "text_weight": gen_text_weight, "dit_tiny": lambda: gen_dit_tiny(ns),
-            "sampler": lambda: gen_sampler(ns), "vae": lambda: gen_vae(ns), "block": lambda: gen_dit_block_3072(ns)}
+            "sampler": lambda: gen_sampler(ns), "vae": lambda: gen_vae(ns), "block": lambda: gen_dit_block_3072(ns),
+            "siglip2": gen_siglip2}
     for k, fn in gens.items():
         if not only or k in only:
             fn()

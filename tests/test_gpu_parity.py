@@ -951,3 +951,88 @@ def test_full_size_t2v_and_i2v_end_to_end():
     assert v1.shape == (3, 49, 704, 1280) and torch.isfinite(v1).all() and v1.abs().max() <= 1.0
     assert lat2.shape == (48, 13, 44, 80) and torch.equal(lat2, lat3)
     assert li.shape == (48, 13, 44, 80) and torch.isfinite(li).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: the SigLIP2 frame ranker (eval_understanding.py:171-240). The towers run on the DiT's GEMM / attention /
+# LayerNorm kernels with bf16 operands and an fp32 residual stream; the golden is transformers' fp32 forward, so the gate is the
+# one that matters for a ranker: cosine similarity of every embedding with the reference embedding, the similarity values, and
+# the ranking itself.
+# ---------------------------------------------------------------------------------------------------------------
+class _StubProcessor:
+    """Stands in for HF's AutoProcessor: 'images' are already NaFlex-patchified tensors, 'text' is looked up in a table."""
+
+    def __init__(self, ids):
+        self.ids = ids
+
+    def __call__(self, images=None, text=None, return_tensors="pt"):
+        if text is not None:
+            return {"input_ids": self.ids[text[0]]}
+        pv = torch.stack([im[0] for im in images])
+        mask = torch.stack([im[1] for im in images])
+        shp = torch.stack([im[2] for im in images])
+        return {"pixel_values": pv, "pixel_attention_mask": mask, "spatial_shapes": shp}
+
+
+def _cos(a, b):
+    return torch.nn.functional.cosine_similarity(a.double().cpu(), b.double().cpu(), dim=-1)
+
+
+def test_siglip2_towers_vs_transformers_golden():
+    from oracle import siglip2 as osl
+    from univid_amd.understanding import Siglip2Model, Siglip2Scorer, mmr_select
+    g = load_golden("siglip2_tiny")
+    m = Siglip2Model(osl.TINY_CFG)
+    m.load_state_dict(osl.make_state_dict(osl.TINY_CFG, int(g["seed"])), strict=False)
+    m = m.to(DEV).eval()
+    fi = m.get_image_features(g["pixel_values"], g["pixel_attention_mask"], g["spatial_shapes"])   # mixed grids, padded images
+    ft = m.get_text_features(g["input_ids"])
+    ftm = m.get_text_features(g["input_ids"], g["attention_mask"])
+    for got, ref, name in ((fi, g["image_features"], "image"), (ft, g["text_features"], "text"), (ftm, g["text_features_masked"], "text+mask")):
+        c = _cos(got, ref)
+        rel = ((got.cpu().double() - ref.double()).norm(dim=-1) / ref.double().norm(dim=-1)).max()
+        assert c.min() > 0.9995 and rel < 2e-2, f"{name}: min cosine {float(c.min()):.6f}, max relative error {float(rel):.3e}"
+    # the scorer facade: rank_frames / emb_imgs / emb_text / mmr_select on the same data
+    frames = [(g["pixel_values"][i], g["pixel_attention_mask"][i], g["spatial_shapes"][i]) for i in range(g["pixel_values"].shape[0])]
+    sc = Siglip2Scorer(device=DEV, model=m, processor=_StubProcessor({"q": g["input_ids"][:1]}))
+    idx, vals = sc.rank_frames(frames, "q", topk=4, bs=4)
+    ref_sims = torch.nn.functional.normalize(g["image_features"], dim=-1) @ torch.nn.functional.normalize(g["text_features"][:1], dim=-1).T
+    assert torch.allclose(torch.tensor(vals), ref_sims.squeeze(-1)[idx].float(), atol=5e-3)
+    assert sorted(vals, reverse=True) == vals and len(idx) == 4
+    gaps = ref_sims.squeeze(-1).sort(descending=True).values
+    if float((gaps[:4] - gaps[1:5]).min()) > 1e-2:          # ranking is only well-defined where the reference scores are separated
+        assert idx == g["rank_idx"].tolist()
+    v = sc.emb_imgs(frames, bs=64)
+    assert torch.allclose(v.norm(dim=-1).cpu(), torch.ones(len(frames)), atol=1e-5)
+    assert sc.rank_frames([], "q", 3) == ([], [])
+    sel = mmr_select(v, sc.emb_text("q"), 3)
+    assert len(sel) == 3 and len(set(sel)) == 3
+    with pytest.raises(NotImplementedError):
+        Siglip2Scorer(device=DEV, model=m, processor=_StubProcessor({}), dtype=torch.float16)
+
+
+def test_siglip2_base_width_vs_oracle():
+    """SigLIP2-base geometry (768-d, 12 heads x 64, 12 layers, patch 16, 256 patches) on 8 frames: HIP towers vs the fp32 CPU
+    oracle with the same deterministic weights (text tower with a small vocabulary: the 256 000-row embedding table is a lookup)."""
+    from oracle import siglip2 as osl
+    from univid_amd.understanding import Siglip2Model
+    cfg = dict(vision=dict(osl.BASE_CFG["vision"]), text=dict(osl.BASE_CFG["text"], vocab_size=1000))
+    sd = osl.make_state_dict(cfg, 1)
+    m = Siglip2Model(cfg)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(DEV).eval()
+    g = torch.Generator().manual_seed(2)
+    B, N = 8, 256
+    pv = torch.randn(B, N, 768, generator=g)
+    mask = torch.ones(B, N, dtype=torch.int64)
+    shapes = torch.tensor([[16, 16]] * B)
+    ids = torch.randint(0, 1000, (1, 64), generator=g)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        ref_i = osl.image_features(sd, cfg, pv, mask, shapes)
+        ref_t = osl.text_features(sd, cfg, ids)
+    got_i, got_t = m.get_image_features(pv, mask, shapes), m.get_text_features(ids)
+    assert _cos(got_i, ref_i).min() > 0.9995 and _cos(got_t, ref_t).min() > 0.9995
+    sims_ref = torch.nn.functional.normalize(ref_i, dim=-1) @ torch.nn.functional.normalize(ref_t, dim=-1).T
+    sims_got = torch.nn.functional.normalize(got_i.cpu(), dim=-1) @ torch.nn.functional.normalize(got_t.cpu(), dim=-1).T
+    assert (sims_ref - sims_got).abs().max() < 5e-3

@@ -191,3 +191,24 @@ def test_checkpoint_roundtrip_diffusers_layout(tmp_path):
     json.dump(cfg, open(bad / "config.json", "w"))
     with pytest.raises(RuntimeError, match="does not match"):
         WanModel.from_pretrained(str(bad))
+
+
+def test_mmr_select_matches_reference_golden():
+    """univid_amd.understanding.mmr_select against the outputs of the reference's own function (eval_understanding.py:225-240)."""
+    from conftest import load_golden
+    from univid_amd.understanding.eval_understanding import mmr_select
+    g = load_golden("siglip2_tiny")
+    for K, lam, key in ((5, 0.5, "mmr_5_05"), (12, 0.2, "mmr_12_02"), (20, 0.9, "mmr_20_09")):
+        assert mmr_select(g["mmr_embs"], g["mmr_query"], K, lam) == g[key].tolist()
+    assert mmr_select(g["mmr_embs"][:0], g["mmr_query"], 3) == []
+
+
+def test_siglip2_state_dict_is_hf_compatible():
+    """Parameter names / shapes are transformers.Siglip2Model's (checkpoints load key for key)."""
+    from oracle import siglip2 as osl
+    from univid_amd.understanding import Siglip2Model
+    m = Siglip2Model(osl.TINY_CFG)
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("logit_")}
+    assert mine == {k: tuple(v) for k, v in osl.state_dict_shapes(osl.TINY_CFG).items()}
+    with pytest.raises(NotImplementedError):
+        Siglip2Model(dict(vision=dict(osl.TINY_CFG["vision"], hidden_size=192, num_attention_heads=3), text=osl.TINY_CFG["text"]))

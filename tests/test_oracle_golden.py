@@ -125,3 +125,23 @@ def test_text_weight_hook_changes_output():
         base = wan_dit.dit_forward(sd, cfg, [g["x"]], g["t_one"], [g["ctx"]], L)[0]
         hooked = wan_dit.dit_forward(sd, cfg, [g["x"]], g["t_one"], [g["ctx"]], L, context_scale_fn=lambda i: m)[0]
     assert torch.equal(base, g["out_one"]) and not torch.equal(base, hooked)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: SigLIP2 ranker. Golden = transformers.Siglip2Model (HF's implementation, which the reference calls) with
+# the deterministic weights; mmr_select golden = the reference's own function.
+# ---------------------------------------------------------------------------------------------------------------
+def test_siglip2_oracle_matches_transformers_golden():
+    from oracle import siglip2
+    g = load_golden("siglip2_tiny")
+    cfg = siglip2.TINY_CFG
+    sd = siglip2.make_state_dict(cfg, int(g["seed"]))
+    fi = siglip2.image_features(sd, cfg, g["pixel_values"], g["pixel_attention_mask"], g["spatial_shapes"])
+    ft = siglip2.text_features(sd, cfg, g["input_ids"])
+    ftm = siglip2.text_features(sd, cfg, g["input_ids"], g["attention_mask"])
+    for got, ref in ((fi, g["image_features"]), (ft, g["text_features"]), (ftm, g["text_features_masked"])):
+        assert (got - ref).abs().max() < 5e-6 * max(1.0, float(ref.abs().max()))
+    idx, vals = siglip2.rank_frames(fi, ft[:1], 4)
+    assert idx == g["rank_idx"].tolist() and torch.allclose(torch.tensor(vals), g["rank_vals"].float(), atol=1e-6)
+    for K, lam, key in ((5, 0.5, "mmr_5_05"), (12, 0.2, "mmr_12_02"), (20, 0.9, "mmr_20_09")):
+        assert siglip2.mmr_select(g["mmr_embs"], g["mmr_query"], K, lam) == g[key].tolist()

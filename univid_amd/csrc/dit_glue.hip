@@ -501,3 +501,25 @@ extern "C" int uv_add_bf16_resid(float* x, long ldx, const void* y, long ldy, in
     UV_CHECK_LAUNCH("uv_add_bf16_resid");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Row-wise L2 normalisation: out[r] = x[r] / max(||x[r]||_2, eps)  (torch.nn.functional.normalize(dim=-1), the cosine
+// scoring of the SigLIP2 ranker: models/BAGEL/eval_understanding.py:185,195). One wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* x, long ldx, float* out, long ldo, int R, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* xr = x + (long)row * ldx;
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) ss += xr[c] * xr[c];
+    const float nrm = fmaxf(sqrtf(wave_sum(ss)), eps);
+    for (int c = lane; c < C; c += 64) out[(long)row * ldo + c] = xr[c] / nrm;
+}
+
+extern "C" int uv_l2_normalize_rows_f32(const float* x, long ldx, float* out, long ldo, int R, int C, float eps, void* stream) {
+    UV_CHECK_ARG(x && out && R > 0 && C > 0, "uv_l2_normalize_rows_f32: bad arguments");
+    hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, R, C, eps);
+    UV_CHECK_LAUNCH("uv_l2_normalize_rows_f32");
+    return 0;
+}
