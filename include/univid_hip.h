@@ -44,6 +44,11 @@ int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw, const void
                     int epilogue, void* out, long ldo, const float* gate, const int32_t* gate_tid, long gate_stride,
                     int tile_cfg, void* stream);
 
+/* uv_gemm_bf16_nt with IEEE fp16 operands, bias and 16-bit outputs (fp32 accumulate): the dtype the reference runs the SigLIP2
+ * ranker in (models/BAGEL/eval_understanding.py:172,181,191: fp16 autocast). Same epilogues; tile_cfg must be 0. */
+int uv_gemm_f16_nt(const void* A, long lda, const void* W, long ldw, const void* bias_f16, int M, int N, int K, int epilogue,
+                   void* out, long ldo, const float* gate, const int32_t* gate_tid, long gate_stride, int tile_cfg, void* stream);
+
 /* C[M,N] = A[M,K] . W[N,K]^T + bias (+ resid), all fp32, exact-f32 MFMA (16x16x4).
  * Replaces Head.head (fp32 island, model.py:286-290) and the VAE's 1x1 convolutions (vae2_2.py:211,249-250,766-767).
  * K % 4 == 0, N % 4 == 0. */
@@ -60,10 +65,14 @@ int uv_gemm_f32_nt(const float* A, long lda, const float* W, long ldw, const flo
 int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                        int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream);
 
+/* uv_flash_attn_bf16 with IEEE fp16 q / k / vt / out (SigLIP2 ranker: transformers' attention under fp16 autocast). */
+int uv_flash_attn_f16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                      int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream);
+
 /* ---- DiT: fused HBM-bound glue ------------------------------------------------------------------------------ */
 /* LayerNorm(no affine) over C then mode 0: y | 1: y*(1+scale[t])+shift[t] (t = tid[row]) | 2: y*w+b.
  * Replaces WanLayerNorm + AdaLN modulation (model.py:93-98, 239-245, 253, 287-290). round_ln=1 rounds y to bf16 first
- * (block 0, whose residual stream is still bf16). out is bf16 (out_bf16=1) or f32. C % 256 == 0, C <= 8192. */
+ * (block 0, whose residual stream is still bf16). out is f32 (out_bf16=0), bf16 (1) or IEEE fp16 (2). C % 256 == 0, C <= 8192. */
 int uv_layernorm_mod(const float* x, long ldx, void* out, long ldo, int L, int C, float eps, int mode, const float* tab,
                      long tab_stride, int shift_off, int scale_off, const int32_t* tid, const float* w, const float* b,
                      int round_ln, int out_bf16, void* stream);

@@ -985,13 +985,15 @@ def test_siglip2_towers_vs_transformers_golden():
     m = Siglip2Model(osl.TINY_CFG)
     m.load_state_dict(osl.make_state_dict(osl.TINY_CFG, int(g["seed"])), strict=False)
     m = m.to(DEV).eval()
-    fi = m.get_image_features(g["pixel_values"], g["pixel_attention_mask"], g["spatial_shapes"])   # mixed grids, padded images
-    ft = m.get_text_features(g["input_ids"])
-    ftm = m.get_text_features(g["input_ids"], g["attention_mask"])
-    for got, ref, name in ((fi, g["image_features"], "image"), (ft, g["text_features"], "text"), (ftm, g["text_features_masked"], "text+mask")):
-        c = _cos(got, ref)
-        rel = ((got.cpu().double() - ref.double()).norm(dim=-1) / ref.double().norm(dim=-1)).max()
-        assert c.min() > 0.9995 and rel < 2e-2, f"{name}: min cosine {float(c.min()):.6f}, max relative error {float(rel):.3e}"
+    for dt, cmin, rmax in ((torch.float16, 0.99999, 4e-3), (torch.bfloat16, 0.9995, 2e-2)):     # fp16 = the reference's dtype
+        m.set_operand_dtype(dt)
+        fi = m.get_image_features(g["pixel_values"], g["pixel_attention_mask"], g["spatial_shapes"])   # mixed grids, padded images
+        ft = m.get_text_features(g["input_ids"])
+        ftm = m.get_text_features(g["input_ids"], g["attention_mask"])
+        for got, ref, name in ((fi, g["image_features"], "image"), (ft, g["text_features"], "text"), (ftm, g["text_features_masked"], "text+mask")):
+            c = _cos(got, ref)
+            rel = ((got.cpu().double() - ref.double()).norm(dim=-1) / ref.double().norm(dim=-1)).max()
+            assert c.min() > cmin and rel < rmax, f"{dt} {name}: min cosine {float(c.min()):.6f}, max relative error {float(rel):.3e}"
     # the scorer facade: rank_frames / emb_imgs / emb_text / mmr_select on the same data
     frames = [(g["pixel_values"][i], g["pixel_attention_mask"][i], g["spatial_shapes"][i]) for i in range(g["pixel_values"].shape[0])]
     sc = Siglip2Scorer(device=DEV, model=m, processor=_StubProcessor({"q": g["input_ids"][:1]}))
@@ -1008,7 +1010,7 @@ def test_siglip2_towers_vs_transformers_golden():
     sel = mmr_select(v, sc.emb_text("q"), 3)
     assert len(sel) == 3 and len(set(sel)) == 3
     with pytest.raises(NotImplementedError):
-        Siglip2Scorer(device=DEV, model=m, processor=_StubProcessor({}), dtype=torch.float16)
+        Siglip2Scorer(device=DEV, model=m, processor=_StubProcessor({}), dtype=torch.float32)
 
 
 def test_siglip2_base_width_vs_oracle():
@@ -1031,8 +1033,60 @@ def test_siglip2_base_width_vs_oracle():
     with torch.no_grad():
         ref_i = osl.image_features(sd, cfg, pv, mask, shapes)
         ref_t = osl.text_features(sd, cfg, ids)
-    got_i, got_t = m.get_image_features(pv, mask, shapes), m.get_text_features(ids)
-    assert _cos(got_i, ref_i).min() > 0.9995 and _cos(got_t, ref_t).min() > 0.9995
     sims_ref = torch.nn.functional.normalize(ref_i, dim=-1) @ torch.nn.functional.normalize(ref_t, dim=-1).T
-    sims_got = torch.nn.functional.normalize(got_i.cpu(), dim=-1) @ torch.nn.functional.normalize(got_t.cpu(), dim=-1).T
-    assert (sims_ref - sims_got).abs().max() < 5e-3
+    for dt, cmin, smax in ((torch.float16, 0.99999, 1e-3), (torch.bfloat16, 0.9995, 5e-3)):
+        m.set_operand_dtype(dt)
+        got_i, got_t = m.get_image_features(pv, mask, shapes), m.get_text_features(ids)
+        assert _cos(got_i, ref_i).min() > cmin and _cos(got_t, ref_t).min() > cmin, (dt, float(_cos(got_i, ref_i).min()))
+        sims_got = torch.nn.functional.normalize(got_i.cpu(), dim=-1) @ torch.nn.functional.normalize(got_t.cpu(), dim=-1).T
+        assert (sims_ref - sims_got).abs().max() < smax, (dt, float((sims_ref - sims_got).abs().max()))
+
+
+def test_fp16_operand_kernels():
+    """The fp16 instantiations of the GEMM (every epilogue, big ping-pong path and small ring path) and of the attention kernel
+    against fp64 references: same structure as the bf16 kernels, IEEE fp16 operands / outputs (the ranker's reference dtype)."""
+    from univid_amd._lib import EPI_BF16, EPI_BF16_T, EPI_F32_FROM_BF16, EPI_GELU_BF16, EPI_RESID_F32
+    F16 = torch.float16
+
+    def ulp16(x):
+        return torch.ldexp(torch.ones_like(x), torch.floor(torch.log2(x.abs().clamp_min(6.2e-5))) - 10)
+
+    for (M, N, K) in [(300, 512, 256), (4100, 1024, 768)]:
+        g = torch.Generator(device=DEV).manual_seed(M)
+        a = (torch.randn(M, K, generator=g, device=DEV) * 0.5).to(F16)
+        w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).to(F16)
+        bias = (torch.randn(N, generator=g, device=DEV) * 0.1).to(F16)
+        acc = a.double() @ w.double().t() + bias.double()
+        y16 = acc.to(F16)
+        out = torch.zeros(M, N, dtype=F16, device=DEV)
+        L().gemm_bf16(a, w, bias, out, EPI_BF16)
+        d = (out.double() - acc).abs()
+        assert (d <= 0.51 * ulp16(acc.float()).double() + 2e-5 * acc.abs().max()).all(), f"f16 gemm {M}x{N}x{K}: {float(d.max()):.3e}"
+        assert (out == y16).float().mean() > 0.999
+        L().gemm_bf16(a, w, bias, out, EPI_GELU_BF16)
+        ref = torch.nn.functional.gelu(y16.float(), approximate="tanh")
+        assert ((out.float() - ref).abs() <= 1.0 * ulp16(ref) + 1.2 * ulp16(y16.float()) + 2e-5 * ref.abs().max()).all()
+        o32 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        L().gemm_bf16(a, w, bias, o32, EPI_F32_FROM_BF16)
+        assert (o32 == y16.float()).float().mean() > 0.999
+        x0 = torch.randn(M, N, generator=g, device=DEV)
+        x = x0.clone()
+        L().gemm_bf16(a, w, bias, x, EPI_RESID_F32)
+        assert ((x - (x0 + y16.float())).abs() <= ulp16(y16.float()) + 1e-6).all()
+        outT = torch.zeros(N, (M + 63) // 64 * 64, dtype=F16, device=DEV)
+        L().gemm_bf16(a, w, bias, outT, EPI_BF16_T)
+        assert (outT[:, :M] == y16.t()).float().mean() > 0.999 and (outT[:, M:] == 0).all()
+        with pytest.raises(Exception):
+            L().gemm_bf16(a, w, bias, out, EPI_BF16, tile_cfg=5)           # explicit tile configs are bf16-only
+    for (Lq, Lk, H, D) in [(300, 300, 2, 64), (1, 256, 12, 64), (260, 200, 2, 128)]:
+        g = torch.Generator(device=DEV).manual_seed(Lq + Lk)
+        C = H * D
+        q, k, v = (torch.randn(n, C, generator=g, device=DEV).to(F16) for n in (Lq, Lk, Lk))
+        qf, kf, vf = (t.double().view(-1, H, D).transpose(0, 1) for t in (q, k, v))
+        truth = (torch.softmax(qf @ kf.transpose(1, 2) / math.sqrt(D), -1) @ vf).transpose(0, 1).reshape(Lq, C)
+        vt = torch.zeros(C, (Lk + 63) // 64 * 64, dtype=F16, device=DEV)
+        vt[:, :Lk] = v.t()
+        out = torch.zeros(Lq, C, dtype=F16, device=DEV)
+        L().flash_attn(q, k, vt, out, Lq, Lk, H, D, 1.0 / math.sqrt(D))
+        err = (out.double() - truth).abs()
+        assert (err <= 3 * ulp16(truth.float()).double() + 5e-4 * truth.abs().max()).all(), f"f16 attention: {float(err.max()):.3e}"

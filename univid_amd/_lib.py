@@ -22,8 +22,10 @@ SIGNATURES = {
     "uv_last_error": [],
     "uv_device_arch": [_c.c_char_p, _I],
     "uv_gemm_bf16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
+    "uv_gemm_f16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
     "uv_gemm_f32_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _P],
     "uv_flash_attn_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
+    "uv_flash_attn_f16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "uv_layernorm_mod": [_P, _L, _P, _L, _I, _I, _F, _I, _P, _L, _I, _I, _P, _P, _P, _I, _I, _P],
     "uv_l2_normalize_rows_f32": [_P, _L, _P, _L, _I, _I, _F, _P],
     "uv_rmsnorm_rope": [_P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _I, _I, _I, _I, _P],
@@ -145,11 +147,12 @@ def _chk(t, dtype, name):
 
 def gemm_bf16(a, w, bias, out, epi, M=None, gate=None, gate_tid=None, tile_cfg=0):
     """a [M,K] bf16, w [N,K] bf16, bias bf16 [N] | None; out per epilogue (see include/univid_hip.h)."""
-    _chk(a, torch.bfloat16, "gemm_bf16.a")
-    _chk(w, torch.bfloat16, "gemm_bf16.w")
+    f16 = a.dtype == torch.float16      # IEEE fp16 operands (SigLIP2 ranker): same kernels, fp16 MFMA / conversions
+    _chk(a, torch.float16 if f16 else torch.bfloat16, "gemm_bf16.a")
+    _chk(w, a.dtype, "gemm_bf16.w")
     M = a.shape[0] if M is None else M
     N, K = w.shape
-    call("uv_gemm_bf16_nt", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), M, N, K, epi, ptr(out), out.stride(0),
+    call("uv_gemm_f16_nt" if f16 else "uv_gemm_bf16_nt", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), M, N, K, epi, ptr(out), out.stride(0),
          ptr(gate), ptr(gate_tid), 0 if gate is None else gate.stride(0), tile_cfg, stream_ptr(), flops=2 * M * N * K)
     return out
 
@@ -166,9 +169,10 @@ def gemm_f32(a, w, bias, out, resid=None, M=None):
 
 def flash_attn(q, k, vt, out, Lq, Lk, H, D, scale, batch=1):
     """q [batch*Lq, C], k [batch*Lk, C], vt [C, >= (batch-1)*Lk + roundup(Lk, 64)] (sample b = columns b*Lk..), out [batch*Lq, C]."""
+    f16 = q.dtype == torch.float16
     for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (out, "out")):
-        _chk(t, torch.bfloat16, "flash_attn." + n)
-    call("uv_flash_attn_bf16", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(vt), vt.stride(0), ptr(out), out.stride(0),
+        _chk(t, q.dtype if f16 else torch.bfloat16, "flash_attn." + n)
+    call("uv_flash_attn_f16" if f16 else "uv_flash_attn_bf16", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(vt), vt.stride(0), ptr(out), out.stride(0),
          batch, Lq, Lk, H, D, float(scale), stream_ptr(), flops=4 * batch * Lq * Lk * H * D)
     return out
 
@@ -178,7 +182,7 @@ def layernorm_mod(x, out, L, C, eps, mode=0, tab=None, shift_off=0, scale_off=0,
     _chk(x, torch.float32, "layernorm_mod.x")
     call("uv_layernorm_mod", ptr(x), x.stride(0), ptr(out), out.stride(0), L, C, float(eps), mode, ptr(tab),
          0 if tab is None else tab.stride(0), shift_off, scale_off, ptr(tid), ptr(w), ptr(b), int(round_ln),
-         int(out.dtype == torch.bfloat16), stream_ptr())
+         2 if out.dtype == torch.float16 else int(out.dtype == torch.bfloat16), stream_ptr())
     return out
 
 

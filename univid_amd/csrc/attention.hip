@@ -56,8 +56,9 @@ __device__ __forceinline__ int perm23(int i) {  // swap bits 2 and 3
 // QB = 32-query blocks per wave. QB = 2 with NW = 4 is the one-wave-per-SIMD form: the wave owns the SIMD's whole 512-entry
 // register file, every K / V^T fragment read from LDS and every LDS-DMA piece serves 64 queries instead of 32, and the
 // softmax VALU work of one block has the other block's MFMAs to hide behind inside the same instruction stream.
-template <int D, int NW, bool STAMP = false, int QB = 1, bool SGB = false>
+template <int D, int NW, bool STAMP = false, int QB = 1, bool SGB = false, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kernel(AttnArgs p, unsigned long long* stamps = nullptr) {
+    static_assert(!(F16 && QB == 2), "the fp16 operand form is built for the default (QB = 1) structure only");
     constexpr int NT = NW * 64;
     constexpr int KROW = 2 * D;                 // bytes per K row in LDS (256 or 128)
     constexpr int KCH = D / 8;                  // 16-B chunks per K row
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
                 for (int kk = 0; kk < NKK; ++kk) {
                     const bf16x8 kf =
                         *(const bf16x8*)(base + T * 32 * KROW + k_row_off + (((2 * kk + h) ^ k_key) << 4));
-                    sacc[b][T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][kk], sacc[b][T], 0, 0, 0);
+                    sacc[b][T] = mfma_32x32x16<F16>(kf, qf[b][kk], sacc[b][T]);
                 }
             }
 
@@ -568,7 +569,12 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
                     for (int j = 0; j < 8; ++j) {
                         const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][T][8 * s + j], p.scale_log2, mneg));
                         psum += pv;
-                        pf[T][s][j] = (__bf16)pv;
+                        if constexpr (F16) {   // fp16 bits carried in the bf16x8 container (P <= 2^UV_ATT_DEFER fits fp16 easily)
+                            bf16_t bits = out16<true>(pv);
+                            pf[T][s][j] = __builtin_bit_cast(__bf16, bits);
+                        } else {
+                            pf[T][s][j] = (__bf16)pv;
+                        }
                     }
             l_run[b] += psum;
             if (STAMP) { asm volatile("" ::"v"(pf[1][1])); }
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
                     for (int s = 0; s < 2; ++s) {
                         const bf16x8 vf =
                             *(const bf16x8*)(base + d * 32 * 128 + v_row_off + (((4 * T + 2 * s + h) ^ v_key) << 4));
-                        oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[T][s], oacc[b][d], 0, 0, 0);
+                        oacc[b][d] = mfma_32x32x16<F16>(vf, pf[T][s], oacc[b][d]);
                     }
         }
 
@@ -634,8 +640,8 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
             for (int d = 0; d < ND; ++d)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    u32x2 o = {pack_bf2(oacc[b][d][4 * g + 0] * inv, oacc[b][d][4 * g + 1] * inv),
-                               pack_bf2(oacc[b][d][4 * g + 2] * inv, oacc[b][d][4 * g + 3] * inv)};
+                    u32x2 o = {pack16_2<F16>(oacc[b][d][4 * g + 0] * inv, oacc[b][d][4 * g + 1] * inv),
+                               pack16_2<F16>(oacc[b][d][4 * g + 2] * inv, oacc[b][d][4 * g + 3] * inv)};
                     *(u32x2*)(op + 32 * d + 8 * g) = o;
                 }
         }
@@ -697,6 +703,34 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
 // Developer diagnostic (not part of include/univid_hip.h): the D=128 kernel with per-segment s_memtime stamps.
 // stamps: device buffer of q_blocks*H*nw*5 uint64 cycle sums [qk, softmax, pv, commit, barrier] per wave. Its fences
 // forbid overlaps the real kernel has: read the SHARES, never its run time.
+// The same kernel with IEEE fp16 q / k / V^T / out (fp32 softmax and accumulation): the SigLIP2 ranker's reference dtype.
+extern "C" int uv_flash_attn_f16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
+                                 void* out, long ldo, int batch, int Lq, int Lk, int H, int head_dim,
+                                 float softmax_scale, void* stream) {
+    UV_CHECK_ARG(q && k && vt && out, "uv_flash_attn_f16: null pointer");
+    UV_CHECK_ARG(head_dim == 128 || head_dim == 64, "uv_flash_attn_f16: head_dim %d unsupported (64 or 128)", head_dim);
+    UV_CHECK_ARG(Lq > 0 && Lk > 0 && H > 0 && batch > 0, "uv_flash_attn_f16: bad shape B=%d Lq=%d Lk=%d H=%d", batch, Lq, Lk, H);
+    UV_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0,
+                 "uv_flash_attn_f16: leading dimensions must be multiples of 8 elements");
+    UV_CHECK_ARG(ldvt >= (long)(batch - 1) * Lk + (long)((Lk + 63) / 64) * 64,
+                 "uv_flash_attn_f16: ldvt=%ld must cover (batch-1)*Lk + Lk rounded up to 64 (batch=%d Lk=%d)", ldvt, batch, Lk);
+    UV_CHECK_ARG(batch == 1 || Lk % 8 == 0, "uv_flash_attn_f16: batch > 1 needs Lk %% 8 == 0 (Lk=%d)", Lk);
+    UV_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0,
+                 "uv_flash_attn_f16: pointers must be 16-byte aligned");
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
+    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
+    a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = batch;
+    a.scale_log2 = softmax_scale * 1.4426950408889634f;
+    a.q_blocks = (Lq + 4 * UV_ATT_QW - 1) / (4 * UV_ATT_QW);
+    const dim3 grid(a.q_blocks * H * batch), block(256);
+    unsigned long long* nostamps = nullptr;
+    if (head_dim == 128) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, false, 1, true, true>), grid, block, 0, (hipStream_t)stream, a, nostamps);
+    else hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 4, false, 1, false, true>), grid, block, 0, (hipStream_t)stream, a, nostamps);
+    UV_CHECK_LAUNCH("uv_flash_attn_f16");
+    return 0;
+}
+
 extern "C" int uvdbg_flash_attn_stamps(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out,
                                        long ldo, int Lq, int Lk, int H, float softmax_scale, int nw,
                                        unsigned long long* stamps, int extra_lds, void* stream) {

@@ -30,6 +30,30 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 // round an f32 through bf16 and back (the value a bf16 tensor would hold)
 __device__ __forceinline__ float round_bf(float x) { return bf2f(f2bf(x)); }
 
+// ---- 16-bit operand type of the MFMA kernels as a compile-time switch: F16 = false -> bf16 (the DiT), true -> IEEE fp16 (the
+// SigLIP2 ranker's reference dtype). The bits travel as bf16_t / bf16x8 either way; only conversions and the MFMA opcode differ.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool F16> __device__ __forceinline__ float in16(bf16_t b) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, b);
+    else return bf2f(b);
+}
+template <bool F16> __device__ __forceinline__ bf16_t out16(float x) {
+    if constexpr (F16) return __builtin_bit_cast(bf16_t, (_Float16)x);
+    else return f2bf(x);
+}
+template <bool F16> __device__ __forceinline__ float round16(float x) { return in16<F16>(out16<F16>(x)); }
+template <bool F16> __device__ __forceinline__ uint32_t pack16_2(float lo, float hi) {
+    return (uint32_t)out16<F16>(lo) | ((uint32_t)out16<F16>(hi) << 16);
+}
+template <bool F16> __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

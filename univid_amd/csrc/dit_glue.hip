@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(LnArgs p) {
                         for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], pa[e]), pb[e]);
                     }
                 }
-                if (p.out_bf16) {
+                if (p.out_bf16 == 2) {   // IEEE fp16 output (SigLIP2 ranker in its reference dtype)
+                    u32x2 o = {pack16_2<true>(y[0], y[1]), pack16_2<true>(y[2], y[3])};
+                    *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;
+                } else if (p.out_bf16) {
                     u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
                     if (UV_LN_NT) __builtin_nontemporal_store(o, (u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c));
                     else *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;

@@ -57,7 +57,7 @@ __device__ __forceinline__ void glds16(const void* g, lds_void* l) {
 // One 16x16 accumulator fragment through the fused epilogue. Plain product (D = Wfrag x Afrag): the lane holds
 // n = nb + 4*fq + {0..3} for m = mb + frow. Transposed product (EPI_BF16_T, D = Afrag x Wfrag): m = mb + 4*fq + {0..3}
 // for n = nb + frow.
-template <int EPI>
+template <int EPI, bool F16 = false>
 __device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, const f32x4& a, int frow, int fq) {
     if (EPI != UV_EPI_BF16_T) {
         const int m = mb + frow, n = nb + 4 * fq;
@@ -67,27 +67,27 @@ __device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, cons
         for (int e = 0; e < 4; ++e) v[e] = a[e];
         if (p.bias) {
             const u32x2 bb = *(const u32x2*)(p.bias + n);
-            v[0] += bf2f((bf16_t)(bb[0] & 0xffff));
-            v[1] += bf2f((bf16_t)(bb[0] >> 16));
-            v[2] += bf2f((bf16_t)(bb[1] & 0xffff));
-            v[3] += bf2f((bf16_t)(bb[1] >> 16));
+            v[0] += in16<F16>((bf16_t)(bb[0] & 0xffff));
+            v[1] += in16<F16>((bf16_t)(bb[0] >> 16));
+            v[2] += in16<F16>((bf16_t)(bb[1] & 0xffff));
+            v[3] += in16<F16>((bf16_t)(bb[1] >> 16));
         }
         if (EPI == UV_EPI_BF16) {
-            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            u32x2 o = {pack16_2<F16>(v[0], v[1]), pack16_2<F16>(v[2], v[3])};
             *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + n) = o;
         } else if (EPI == UV_EPI_GELU_BF16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f32(round_bf(v[e]));
-            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f32(round16<F16>(v[e]));
+            u32x2 o = {pack16_2<F16>(v[0], v[1]), pack16_2<F16>(v[2], v[3])};
             *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + n) = o;
         } else if (EPI == UV_EPI_F32_FROM_BF16) {
-            f32x4 o = {round_bf(v[0]), round_bf(v[1]), round_bf(v[2]), round_bf(v[3])};
+            f32x4 o = {round16<F16>(v[0]), round16<F16>(v[1]), round16<F16>(v[2]), round16<F16>(v[3])};
             *(f32x4*)((float*)p.out + (long)m * p.ldo + n) = o;
         } else if (EPI == UV_EPI_RESID_F32) {
             float* xp = (float*)p.out + (long)m * p.ldo + n;
             f32x4 x = *(const f32x4*)xp;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = __fadd_rn(x[e], round_bf(v[e]));
+            for (int e = 0; e < 4; ++e) x[e] = __fadd_rn(x[e], round16<F16>(v[e]));
             *(f32x4*)xp = x;
         } else if (EPI == UV_EPI_GATE_RESID_F32) {
             const int t = p.gate_tid ? p.gate_tid[m] : 0;
@@ -95,19 +95,19 @@ __device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, cons
             float* xp = (float*)p.out + (long)m * p.ldo + n;
             f32x4 x = *(const f32x4*)xp;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = __fadd_rn(x[e], __fmul_rn(round_bf(v[e]), g[e]));
+            for (int e = 0; e < 4; ++e) x[e] = __fadd_rn(x[e], __fmul_rn(round16<F16>(v[e]), g[e]));
             *(f32x4*)xp = x;
         }
     } else {
         const int n = nb + frow, m = mb + 4 * fq;
         if (n >= p.N || m >= p.M) return;  // M is padded to a multiple of 4 by the caller's ldo
-        const float b = p.bias ? bf2f(p.bias[n]) : 0.f;
+        const float b = p.bias ? in16<F16>(p.bias[n]) : 0.f;
         bf16_t* op = (bf16_t*)p.out + (long)n * p.ldo + m;
         if (m + 3 < p.M) {
-            u32x2 o = {pack_bf2(a[0] + b, a[1] + b), pack_bf2(a[2] + b, a[3] + b)};
+            u32x2 o = {pack16_2<F16>(a[0] + b, a[1] + b), pack16_2<F16>(a[2] + b, a[3] + b)};
             *(u32x2*)op = o;
         } else {
-            for (int e = 0; e < 4 && m + e < p.M; ++e) op[e] = f2bf(a[e] + b);
+            for (int e = 0; e < 4 && m + e < p.M; ++e) op[e] = out16<F16>(a[e] + b);
         }
     }
 }
@@ -117,7 +117,7 @@ __device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, cons
 // the token->gate-row indices of all rows are fetched first, then the x / gate loads of fragment f+D are issued before
 // fragment f is stored. Written in this order by hand because the compiler must assume the x stores alias the later
 // loads and otherwise serialises {index load -> gate/x load -> store} per row block (4-8 dependent HBM round trips per tile).
-template <int EPI, int NF, int D>
+template <int EPI, int NF, int D, bool F16 = false>
 __device__ __forceinline__ void epi_rmw_pipe(const GemmArgs& p, const int (&mb)[NF], const int (&nb)[NF], const f32x4 (&acc)[NF],
                                              int frow, int fq) {
     static_assert(EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32, "rmw epilogues only");
@@ -145,20 +145,20 @@ __device__ __forceinline__ void epi_rmw_pipe(const GemmArgs& p, const int (&mb)[
         const int slot = f % D;
         const int m = mb[f] + frow, n = nb[f] + 4 * fq;
         float v[4];
-        v[0] = acc[f][0] + bf2f((bf16_t)(bb[slot][0] & 0xffff));
-        v[1] = acc[f][1] + bf2f((bf16_t)(bb[slot][0] >> 16));
-        v[2] = acc[f][2] + bf2f((bf16_t)(bb[slot][1] & 0xffff));
-        v[3] = acc[f][3] + bf2f((bf16_t)(bb[slot][1] >> 16));
+        v[0] = acc[f][0] + in16<F16>((bf16_t)(bb[slot][0] & 0xffff));
+        v[1] = acc[f][1] + in16<F16>((bf16_t)(bb[slot][0] >> 16));
+        v[2] = acc[f][2] + in16<F16>((bf16_t)(bb[slot][1] & 0xffff));
+        v[3] = acc[f][3] + in16<F16>((bf16_t)(bb[slot][1] >> 16));
         f32x4 x = xb[slot];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            x[e] = GATE ? __fadd_rn(x[e], __fmul_rn(round_bf(v[e]), gb[slot][e])) : __fadd_rn(x[e], round_bf(v[e]));
+            x[e] = GATE ? __fadd_rn(x[e], __fmul_rn(round16<F16>(v[e]), gb[slot][e])) : __fadd_rn(x[e], round16<F16>(v[e]));
         if (m < p.M && n < p.N) *(f32x4*)((float*)p.out + (long)m * p.ldo + n) = x;
         if (f + D < NF) issue(f + D, slot);
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NS = 2>
+template <int BM, int BN, int WM, int WN, int EPI, int NS = 2, bool F16 = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int NT = NW * 64;
@@ -270,9 +270,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
                     if (TRANS)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], wf[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_16x16x32<F16>(af[j], wf[i], acc[i][j]);
                     else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_16x16x32<F16>(wf[i], af[j], acc[i][j]);
                 }
         }
     };
@@ -326,13 +326,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
                 nb[j * TN + i] = n0 + wn * (BN / WN) + i * 16;
                 av[j * TN + i] = acc[i][j];
             }
-        epi_rmw_pipe<EPI, NF, (NF >= 8 ? 4 : 2)>(p, mb, nb, av, frow, fq);
+        epi_rmw_pipe<EPI, NF, (NF >= 8 ? 4 : 2), F16>(p, mb, nb, av, frow, fq);
     } else {
 #pragma unroll
         for (int j = 0; j < TM; ++j)
 #pragma unroll
             for (int i = 0; i < TN; ++i)
-                epi_frag<EPI>(p, m0 + wm * (BM / WM) + j * 16, n0 + wn * (BN / WN) + i * 16, acc[i][j], frow, fq);
+                epi_frag<EPI, F16>(p, m0 + wm * (BM / WM) + j * 16, n0 + wn * (BN / WN) + i * 16, acc[i][j], frow, fq);
     }
 }
 
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
 #define UV_SB() __builtin_amdgcn_s_barrier()
 #define UV_SCHED() __builtin_amdgcn_sched_barrier(0)
 
-template <int EPI, int VAR = 0>
+template <int EPI, int VAR = 0, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     constexpr bool TRANS = (EPI == UV_EPI_BF16_T);
     constexpr int HALF = 16384;      // one half-tile: 128 rows x 128 B
@@ -446,9 +446,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
         if (TRANS)                                                                                \
-            acc[HN][HM][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][KS], WF[i][KS], acc[HN][HM][i][j], 0, 0, 0); \
+            acc[HN][HM][i][j] = mfma_16x16x32<F16>(af[j][KS], WF[i][KS], acc[HN][HM][i][j]); \
         else                                                                                      \
-            acc[HN][HM][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i][KS], af[j][KS], acc[HN][HM][i][j], 0, 0, 0); \
+            acc[HN][HM][i][j] = mfma_16x16x32<F16>(WF[i][KS], af[j][KS], acc[HN][HM][i][j]); \
     }
 #define UV_MFMA_Q(HM, HN, WF)                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                                \
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
                         nb[f] = n0 + hn * 128 + wc * 32 + i * 16;
                         av[f] = acc[hn][hm][i][j];
                     }
-        epi_rmw_pipe<EPI, 32, 8>(p, mb, nb, av, frow, fq);
+        epi_rmw_pipe<EPI, 32, 8, F16>(p, mb, nb, av, frow, fq);
     } else {
 #pragma unroll
         for (int hm = 0; hm < 2; ++hm)
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
                 for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        epi_frag<EPI>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], frow, fq);
+                        epi_frag<EPI, F16>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], frow, fq);
     }
     if constexpr (VAR >= 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     }
 }
 
-template <int VAR = 0>
+template <int VAR = 0, bool F16 = false>
 static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
     GemmArgs a = a0;
     a.tiles_m = (a.M + 255) / 256;
@@ -665,7 +665,7 @@ static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
     const size_t lds = 128 * 1024;
 #define UV_LAUNCH8(E)                                                                              \
     case E: {                                                                                      \
-        auto kern = gemm_bf16_8ph_kernel<E, VAR>;                                                    \
+        auto kern = gemm_bf16_8ph_kernel<E, VAR, F16>;                                               \
         static bool attr_set = false;                                                              \
         if (!attr_set) {                                                                           \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
@@ -691,7 +691,7 @@ static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NS = 2>
+template <int BM, int BN, int WM, int WN, int NS = 2, bool F16 = false>
 static int launch_cfg(const GemmArgs& a0, int epi, hipStream_t stream) {
     GemmArgs a = a0;
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -700,7 +700,7 @@ static int launch_cfg(const GemmArgs& a0, int epi, hipStream_t stream) {
     const size_t lds = NS * (BM + BN) * 128;
 #define UV_LAUNCH(E)                                                                               \
     case E: {                                                                                      \
-        auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, E, NS>;                                     \
+        auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, E, NS, F16>;                                \
         static bool attr_set = false;                                                              \
         if (!attr_set) {                                                                           \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
@@ -736,15 +736,17 @@ static int num_cus() {
     return n;
 }
 
+template <bool F16>
 static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStream_t s);
 
 // Rows that fill whole rounds of 256x256 tiles go to the big-tile kernel; the leftover rows (which would otherwise cost a
 // whole extra round on a fraction of the CUs) run as 128x128 tiles. Same arithmetic per element either way.
+template <bool F16>
 static int launch_m_split(const GemmArgs& a, int epilogue, int main_cfg, hipStream_t s) {
     const long tiles_n = (a.N + 255) / 256, tiles_m = (a.M + 255) / 256;
     const long rounds = tiles_m * tiles_n / num_cus();
     const long m_main = rounds * num_cus() / tiles_n * 256;
-    if (rounds == 0 || m_main <= 0 || m_main >= a.M) return launch_by_cfg(a, epilogue, main_cfg, s);
+    if (rounds == 0 || m_main <= 0 || m_main >= a.M) return launch_by_cfg<F16>(a, epilogue, main_cfg, s);
     GemmArgs am = a, at = a;
     am.M = (int)m_main;
     at.M = a.M - (int)m_main;
@@ -753,14 +755,13 @@ static int launch_m_split(const GemmArgs& a, int epilogue, int main_cfg, hipStre
     if (epilogue == UV_EPI_BF16_T) at.out = (bf16_t*)a.out + m_main;
     else if (epilogue == UV_EPI_BF16 || epilogue == UV_EPI_GELU_BF16) at.out = (bf16_t*)a.out + m_main * a.ldo;
     else at.out = (float*)a.out + m_main * a.ldo;
-    const int rc = launch_by_cfg(am, epilogue, main_cfg, s);
-    return rc ? rc : launch_by_cfg(at, epilogue, 12, s);
+    const int rc = launch_by_cfg<F16>(am, epilogue, main_cfg, s);
+    return rc ? rc : launch_by_cfg<F16>(at, epilogue, 12, s);
 }
 
-extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw, const void* bias_bf16,
-                               int M, int N, int K, int epilogue, void* out, long ldo,
-                               const float* gate, const int32_t* gate_tid, long gate_stride,
-                               int tile_cfg, void* stream) {
+template <bool F16>
+static int gemm_entry(const void* A, long lda, const void* W, long ldw, const void* bias_bf16, int M, int N, int K, int epilogue,
+                      void* out, long ldo, const float* gate, const int32_t* gate_tid, long gate_stride, int tile_cfg, void* stream) {
     UV_CHECK_ARG(A && W && out, "uv_gemm_bf16_nt: null pointer");
     UV_CHECK_ARG(M > 0 && N > 0 && K > 0, "uv_gemm_bf16_nt: bad shape M=%d N=%d K=%d", M, N, K);
     UV_CHECK_ARG(K % UV_BK == 0, "uv_gemm_bf16_nt: K=%d must be a multiple of %d", K, UV_BK);
@@ -783,14 +784,32 @@ extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw,
         const int main_cfg = 7;
         const long tiles = (long)((M + 255) / 256) * (N / 256);
         const long rounds = tiles / num_cus(), rest = tiles - rounds * num_cus();
-        if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) return launch_m_split(a, epilogue, main_cfg, s);
-        return launch_by_cfg(a, epilogue, main_cfg, s);
+        if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) return launch_m_split<F16>(a, epilogue, main_cfg, s);
+        return launch_by_cfg<F16>(a, epilogue, main_cfg, s);
     }
-    if (tile_cfg == 8) return launch_m_split(a, epilogue, 7, s);
-    if (tile_cfg == 9) return launch_m_split(a, epilogue, 5, s);
-    return launch_by_cfg(a, epilogue, tile_cfg, s);
+    if (tile_cfg == 8) return launch_m_split<F16>(a, epilogue, 7, s);
+    if (tile_cfg == 9) return launch_m_split<F16>(a, epilogue, 5, s);
+    return launch_by_cfg<F16>(a, epilogue, tile_cfg, s);
 }
 
+extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw, const void* bias_bf16,
+                               int M, int N, int K, int epilogue, void* out, long ldo,
+                               const float* gate, const int32_t* gate_tid, long gate_stride,
+                               int tile_cfg, void* stream) {
+    return gemm_entry<false>(A, lda, W, ldw, bias_bf16, M, N, K, epilogue, out, ldo, gate, gate_tid, gate_stride, tile_cfg, stream);
+}
+
+// The same GEMM with IEEE fp16 operands / bias / 16-bit outputs (fp32 accumulate): the SigLIP2 ranker's reference dtype
+// (models/BAGEL/eval_understanding.py:172). Only the automatic tile choice (tile_cfg 0) is built for fp16.
+extern "C" int uv_gemm_f16_nt(const void* A, long lda, const void* W, long ldw, const void* bias_f16,
+                              int M, int N, int K, int epilogue, void* out, long ldo,
+                              const float* gate, const int32_t* gate_tid, long gate_stride,
+                              int tile_cfg, void* stream) {
+    UV_CHECK_ARG(tile_cfg == 0, "uv_gemm_f16_nt: only tile_cfg 0 (automatic) is built for fp16 operands");
+    return gemm_entry<true>(A, lda, W, ldw, bias_f16, M, N, K, epilogue, out, ldo, gate, gate_tid, gate_stride, tile_cfg, stream);
+}
+
+template <bool F16>
 static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStream_t s) {
     const int M = a.M, N = a.N, K = a.K;
     switch (tile_cfg) {
@@ -799,34 +818,36 @@ static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStrea
                 // few tiles (at most ~2 per CU): 8 waves on a 4-stage ring hide the DMA/LDS latency that one 4-wave
                 // workgroup per CU leaves exposed; many tiles: 4-wave workgroups, 2-3 resident per CU
                 const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-                if (t128 <= 2 * num_cus()) return launch_cfg<128, 128, 4, 2, 4>(a, epilogue, s);
-                return launch_cfg<128, 128, 2, 2>(a, epilogue, s);
+                if (t128 <= 2 * num_cus()) return launch_cfg<128, 128, 4, 2, 4, F16>(a, epilogue, s);
+                return launch_cfg<128, 128, 2, 2, 2, F16>(a, epilogue, s);
             }
             const long tm = (M + 255) / 256;
             const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
             // cost ~ rounds x tile area; 256x192 tiles carry 3/4 of the work of 256x256 at slightly lower efficiency
             const double c256 = (double)((t256 + 255) / 256) * 1.00, c192 = (double)((t192 + 255) / 256) * 0.78;
-            if (N % 192 == 0 && c192 < c256 && K <= 4096) return launch_cfg<256, 192, 4, 4>(a, epilogue, s);
-            return launch_cfg<256, 256, 4, 4>(a, epilogue, s);
+            if (!F16 && N % 192 == 0 && c192 < c256 && K <= 4096) return launch_cfg<256, 192, 4, 4>(a, epilogue, s);
+            return launch_cfg<256, 256, 4, 4, 2, F16>(a, epilogue, s);
         }
-        case 1: return launch_cfg<128, 128, 2, 2>(a, epilogue, s);
-        case 2: return launch_cfg<256, 256, 2, 4>(a, epilogue, s);
-        case 3: return launch_cfg<256, 128, 4, 2>(a, epilogue, s);
-        case 4: return launch_cfg<256, 192, 2, 4>(a, epilogue, s);
-        case 5: return launch_cfg<256, 256, 4, 4>(a, epilogue, s);
-        case 6: return launch_cfg<256, 192, 4, 4>(a, epilogue, s);
-        case 10: return launch_cfg<128, 128, 2, 2, 4>(a, epilogue, s);
-        case 11: return launch_cfg<128, 128, 2, 4, 4>(a, epilogue, s);
-        case 12: return launch_cfg<128, 128, 4, 2, 4>(a, epilogue, s);
-        case 13: return launch_cfg<128, 128, 2, 4, 2>(a, epilogue, s);
+        case 1: if constexpr (!F16) return launch_cfg<128, 128, 2, 2>(a, epilogue, s); else break;
+        case 2: if constexpr (!F16) return launch_cfg<256, 256, 2, 4>(a, epilogue, s); else break;
+        case 3: if constexpr (!F16) return launch_cfg<256, 128, 4, 2>(a, epilogue, s); else break;
+        case 4: if constexpr (!F16) return launch_cfg<256, 192, 2, 4>(a, epilogue, s); else break;
+        case 5: if constexpr (!F16) return launch_cfg<256, 256, 4, 4>(a, epilogue, s); else break;
+        case 6: if constexpr (!F16) return launch_cfg<256, 192, 4, 4>(a, epilogue, s); else break;
+        case 10: if constexpr (!F16) return launch_cfg<128, 128, 2, 2, 4>(a, epilogue, s); else break;
+        case 11: if constexpr (!F16) return launch_cfg<128, 128, 2, 4, 4>(a, epilogue, s); else break;
+        case 12: return launch_cfg<128, 128, 4, 2, 4, F16>(a, epilogue, s);
+        case 13: if constexpr (!F16) return launch_cfg<128, 128, 2, 4, 2>(a, epilogue, s); else break;
         case 7:
             UV_CHECK_ARG(K % 128 == 0 && K >= 256, "uv_gemm_bf16_nt: tile_cfg 7 needs K %% 128 == 0 and K >= 256 (K=%d)", K);
-            return launch_8ph<5>(a, epilogue, s);
-        case 14: return launch_8ph<0>(a, epilogue, s);   // the 4-phase-per-K-tile schedule (A/B reference, stamped diagnostics)
+            return launch_8ph<5, F16>(a, epilogue, s);
+        case 14: if constexpr (!F16) return launch_8ph<0>(a, epilogue, s); else break;   // the 4-phase-per-K-tile schedule (A/B reference)
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown tile_cfg %d", tile_cfg);
             return -1;
     }
+    uv_set_error("uv_gemm_f16_nt: tile_cfg %d is not built for fp16 operands", tile_cfg);
+    return -1;
 }
 
 // Diagnostic (not part of the public ABI, used by tools/gemm_bench.py --stamps): the ping-pong kernel with in-kernel cycle

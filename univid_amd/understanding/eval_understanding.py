@@ -23,11 +23,10 @@ def _normalize(x: torch.Tensor) -> torch.Tensor:
 
 
 class Siglip2Scorer:
-    def __init__(self, ckpt: str = None, device: str = "cuda:0", dtype: torch.dtype = torch.bfloat16, *, model: Siglip2Model = None,
+    def __init__(self, ckpt: str = None, device: str = "cuda:0", dtype: torch.dtype = torch.float16, *, model: Siglip2Model = None,
                  processor=None):
-        if dtype != torch.bfloat16:
-            raise NotImplementedError("this build computes the SigLIP2 towers with bf16 operands (fp32 accumulation and residual "
-                                      "stream): pass dtype=torch.bfloat16")
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise NotImplementedError("the SigLIP2 towers run with fp16 (reference default) or bf16 operands, fp32 accumulation")
         self.device = torch.device(device)
         self.dtype = dtype
         if processor is None:
@@ -41,7 +40,7 @@ class Siglip2Scorer:
             if ckpt is None:
                 raise ValueError("pass model= (a Siglip2Model) or ckpt=")
             model = Siglip2Model.from_pretrained(ckpt)
-        self.model = model.to(self.device).eval()
+        self.model = model.to(self.device).eval().set_operand_dtype(dtype)
 
     @torch.no_grad()
     def emb_text(self, q: str) -> torch.Tensor:

@@ -7,10 +7,9 @@ encoder layers (MHA with bias, gelu_pytorch_tanh MLP), post LayerNorm, multi-hea
 text: token + position embeddings, the same encoder without a causal mask, final LayerNorm, LAST token, `head` Linear.
 
 Parameter names and shapes are HF's, so a `Siglip2Model` state dict loads key for key. Compute: the DiT's kernels -
-`uv_gemm_bf16_nt` (bias / GELU-tanh / fp32-residual / transposed-V epilogues), `uv_flash_attn_bf16` (head_dim 64),
-`uv_layernorm_mod` (affine). Operands are bf16 with fp32 accumulation and an fp32 residual stream (the reference runs the HF
-model under fp16 autocast, `Siglip2Scorer(dtype=...)`; this build supports dtype=torch.bfloat16 - fp16 operands would need fp16
-MFMA instantiations of the two kernels). Padded patches / tokens are never computed: only the valid prefix of every sequence is
+`uv_gemm_{f16,bf16}_nt` (bias / GELU-tanh / fp32-residual / transposed-V epilogues), `uv_flash_attn_{f16,bf16}` (head_dim 64),
+`uv_layernorm_mod` (affine). Operands are fp16 (the reference runs the HF model under fp16 autocast,
+`Siglip2Scorer(dtype=torch.float16)`) or bf16, with fp32 accumulation and an fp32 residual stream. Padded patches / tokens are never computed: only the valid prefix of every sequence is
 embedded, attended and pooled, which is what the reference's attention masks amount to.
 """
 import json
@@ -31,15 +30,15 @@ def _round_up(a, b):
 
 
 class _W:
-    """bf16 operand copies of one Linear (weight [N, K] with K padded to the GEMM's 64 granularity, bias)."""
+    """16-bit operand copies of one Linear (weight [N, K] with K padded to the GEMM's 64 granularity, bias)."""
     __slots__ = ("w", "b")
 
-    def __init__(self, weight, bias):
+    def __init__(self, weight, bias, op):
         w = weight.detach()
         if w.shape[1] % 64:
             w = torch.nn.functional.pad(w, (0, 64 - w.shape[1] % 64))
-        self.w = w.to(BF16).contiguous()
-        self.b = None if bias is None else bias.detach().to(BF16).contiguous()
+        self.w = w.to(op).contiguous()
+        self.b = None if bias is None else bias.detach().to(op).contiguous()
 
 
 class Siglip2MLP(nn.Module):
@@ -67,18 +66,21 @@ class Siglip2EncoderLayer(nn.Module):
         self.layer_norm2 = nn.LayerNorm(hidden, eps=eps)
         self.mlp = Siglip2MLP(hidden, inter)
         self._p = None
+        self._op = BF16
 
-    def prepare(self):
+    def prepare(self, op=BF16):
         a = self.self_attn
-        self._p = {n: _W(getattr(a, n).weight, getattr(a, n).bias) for n in ("q_proj", "k_proj", "v_proj", "out_proj")}
-        self._p["fc1"] = _W(self.mlp.fc1.weight, self.mlp.fc1.bias)
-        self._p["fc2"] = _W(self.mlp.fc2.weight, self.mlp.fc2.bias)
+        self._op = op
+        self._p = {n: _W(getattr(a, n).weight, getattr(a, n).bias, op) for n in ("q_proj", "k_proj", "v_proj", "out_proj")}
+        self._p["fc1"] = _W(self.mlp.fc1.weight, self.mlp.fc1.bias, op)
+        self._p["fc2"] = _W(self.mlp.fc2.weight, self.mlp.fc2.bias, op)
 
     def run(self, x, batch, Lq, Lk):
         """x fp32 [batch*Lq, h] residual stream, updated in place; the keys / values of sample b are its first Lk rows."""
         p, a = self._p, self.self_attn
         h, H, D = x.shape[1], a.num_heads, a.head_dim
         dev = x.device
+        BF16 = self._op          # operand dtype of this pass (bf16 or fp16); the name is kept for brevity below
         M = batch * Lq
         y = torch.empty(M, h, dtype=BF16, device=dev)
         _lib.layernorm_mod(x, y, M, h, self.layer_norm1.eps, mode=2, w=self.layer_norm1.weight, b=self.layer_norm1.bias)
@@ -157,24 +159,28 @@ class Siglip2VisionModel(nn.Module):
         self.post_layernorm = nn.LayerNorm(c["hidden_size"], eps=c["layer_norm_eps"])
         self.head = Siglip2PoolingHead(c)
         self._p = None
+        self.op_dtype = BF16
 
-    def prepare(self):
+    def prepare(self, op=BF16):
         for l in self.encoder.layers:
-            l.prepare()
+            l.prepare(op)
         h = self.cfg["hidden_size"]
+        self._op = op
         W, B = self.head.attention.in_proj_weight, self.head.attention.in_proj_bias
-        self._p = {"patch": _W(self.embeddings.patch_embedding.weight, self.embeddings.patch_embedding.bias),
-                   "hq": _W(W[:h], B[:h]), "hk": _W(W[h:2 * h], B[h:2 * h]), "hv": _W(W[2 * h:], B[2 * h:]),
-                   "ho": _W(self.head.attention.out_proj.weight, self.head.attention.out_proj.bias),
-                   "hfc1": _W(self.head.mlp.fc1.weight, self.head.mlp.fc1.bias), "hfc2": _W(self.head.mlp.fc2.weight, self.head.mlp.fc2.bias),
-                   "probe": self.head.probe.detach().reshape(1, h).to(BF16).contiguous()}
+        self._p = {"patch": _W(self.embeddings.patch_embedding.weight, self.embeddings.patch_embedding.bias, op),
+                   "hq": _W(W[:h], B[:h], op), "hk": _W(W[h:2 * h], B[h:2 * h], op), "hv": _W(W[2 * h:], B[2 * h:], op),
+                   "ho": _W(self.head.attention.out_proj.weight, self.head.attention.out_proj.bias, op),
+                   "hfc1": _W(self.head.mlp.fc1.weight, self.head.mlp.fc1.bias, op),
+                   "hfc2": _W(self.head.mlp.fc2.weight, self.head.mlp.fc2.bias, op),
+                   "probe": self.head.probe.detach().reshape(1, h).to(op).contiguous()}
 
     def pooled(self, pixel_values, pixel_attention_mask, spatial_shapes):
         """[B, N, 3*p*p], [B, N], [B, 2] -> pooler_output [B, h] fp32. Images with the same grid run as one stacked pass."""
         if self._p is None:
-            self.prepare()
+            self.prepare(self.op_dtype)
         dev = self.embeddings.patch_embedding.weight.device
         c, p = self.cfg, self._p
+        BF16 = self._op
         h, H = c["hidden_size"], c["num_attention_heads"]
         D = h // H
         B = pixel_values.shape[0]
@@ -244,16 +250,19 @@ class Siglip2TextModel(nn.Module):
         self.final_layer_norm = nn.LayerNorm(c["hidden_size"], eps=c["layer_norm_eps"])
         self.head = nn.Linear(c["hidden_size"], c["projection_size"])
         self._p = None
+        self.op_dtype = BF16
 
-    def prepare(self):
+    def prepare(self, op=BF16):
         for l in self.encoder.layers:
-            l.prepare()
-        self._p = {"head": _W(self.head.weight, self.head.bias)}
+            l.prepare(op)
+        self._op = op
+        self._p = {"head": _W(self.head.weight, self.head.bias, op)}
 
     def pooled(self, input_ids, attention_mask=None):
         """[B, T] token ids (right-padded to max_length by the tokenizer) -> [B, projection] fp32: last token's state -> head."""
         if self._p is None:
-            self.prepare()
+            self.prepare(self.op_dtype)
+        BF16 = self._op
         dev = self.head.weight.device
         ids = input_ids.to(dev)
         B, T = ids.shape
@@ -282,7 +291,7 @@ class Siglip2TextModel(nn.Module):
 class Siglip2Model(nn.Module):
     """`transformers.Siglip2Model` surface used by the ranker: get_image_features / get_text_features, .to(device), .eval()."""
 
-    def __init__(self, config: dict):
+    def __init__(self, config: dict, dtype: torch.dtype = BF16):
         super().__init__()
         self.config = {"vision": dict(config["vision"]), "text": dict(config["text"])}
         for c in (self.config["vision"], self.config["text"]):
@@ -292,7 +301,17 @@ class Siglip2Model(nn.Module):
         self.text_model = Siglip2TextModel(self.config["text"])
         self.logit_scale = nn.Parameter(torch.zeros(1))
         self.logit_bias = nn.Parameter(torch.zeros(1))
+        self.set_operand_dtype(dtype)
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
+
+    def set_operand_dtype(self, dtype):
+        """torch.bfloat16 or torch.float16: the 16-bit operand type of every GEMM / attention (fp32 accumulation and residual
+        stream either way). The reference runs the HF model under fp16 autocast (eval_understanding.py:172)."""
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise NotImplementedError(f"operand dtype {dtype}: bfloat16 or float16")
+        self.vision_model.op_dtype = self.text_model.op_dtype = dtype
+        self.invalidate()
+        return self
 
     def invalidate(self):
         self.vision_model._p = None
