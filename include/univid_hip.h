@@ -107,6 +107,11 @@ int uv_add_bf16_resid(float* x, long ldx, const void* y, long ldy, int L, int C,
  * (models/BAGEL/eval_understanding.py:185,195). */
 int uv_l2_normalize_rows_f32(const float* x, long ldx, float* out, long ldo, int R, int C, float eps, void* stream);
 
+/* ContextProjector glue (models/model_pipeline.py:1516-1523, 1532-1549; the module is bf16): exact (erf) GELU of a bf16 tensor,
+ * and F.interpolate(mode='linear', align_corners=False) along the token axis of [Lin, C] bf16 rows. */
+int uv_gelu_erf_bf16(const void* in, void* out, long n, void* stream);
+int uv_interp_linear_rows_bf16(const void* in, long ldi, void* out, long ldo, int Lin, int Lout, int C, void* stream);
+
 /* ---- sampler (CFG + flow UniPC order 2 / bh2 / predict-x0) -------------------------------------------------- */
 /* noise_pred = uncond + gs*(cond - uncond) (textimage2video.py:385); x0 = sample - sigma*noise_pred
  * (fm_solvers_unipc.py:323). noise_pred may be NULL. */

@@ -196,3 +196,22 @@ def ref_mmr_select(embs, query_emb, K, lam=0.5):
     ns = {"torch": torch, "List": List}
     exec(compile(ast.Module(body=[fn], type_ignores=[]), "eval_understanding.py:mmr_select", "exec"), ns)
     return ns["mmr_select"](embs, query_emb, K, lam)
+
+
+def ref_context_projector(config):
+    """Builds the reference's ContextProjector (models/model_pipeline.py:1506-1574) from its source alone (the module's file
+    imports cv2 / torchvision / easydict at top level and cannot be imported here)."""
+    import ast
+    import contextlib
+    import io
+    from typing import Dict, List
+    import torch.nn as nn
+    import torch.nn.functional as F
+    path = os.path.join(REF_ROOT, "models", "model_pipeline.py")
+    tree = ast.parse(open(path).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "ContextProjector"][0]
+    ns = {"torch": torch, "nn": nn, "F": F, "List": List, "Dict": Dict, "GLOBAL_TARGET_DTYPE": torch.bfloat16,
+          "CrossAttentionConfig": object}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), "model_pipeline.py:ContextProjector", "exec"), ns)
+    with contextlib.redirect_stdout(io.StringIO()):
+        return ns["ContextProjector"](config)

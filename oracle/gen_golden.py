@@ -19,7 +19,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import _refimport, sampler, siglip2, unipc, wan_dit, wan_vae  # noqa: E402
+from oracle import _refimport, projector, sampler, siglip2, unipc, wan_dit, wan_vae  # noqa: E402
 from univid_amd import detinit  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -291,6 +291,29 @@ def gen_siglip2():
          mmr_embs=embs, mmr_query=qe, mmr_5_05=np.asarray(mm[0]), mmr_12_02=np.asarray(mm[1]), mmr_20_09=np.asarray(mm[2]))
 
 
+def gen_projector():
+    """ContextProjector (model_pipeline.py:1506-1574) at reduced widths: the reference class itself, executed from its source."""
+    import contextlib
+    import io
+    import types
+    print("context projector")
+    cfg = types.SimpleNamespace(bagel_hidden_dim=128, wan_text_dim=256, wan_text_length=32, use_semantic_alignment=False)
+    ref = _refimport.ref_context_projector(cfg).eval()
+    sd = projector.make_state_dict(cfg.bagel_hidden_dim, cfg.wan_text_dim, seed=4)
+    ref.load_state_dict(sd)
+    g = torch.Generator().manual_seed(6)
+    outs = {}
+    for L in (32, 20, 77):        # equal to / shorter / longer than the target length
+        tok = torch.randn(2, L, cfg.bagel_hidden_dim, generator=g)
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            r = ref(tok)
+        o = projector.forward(sd, tok, cfg.wan_text_length)
+        assert all(torch.equal(a, b) for a, b in zip(r, o)), L
+        outs[f"tokens_{L}"] = tok
+        outs[f"out_{L}"] = torch.stack(r)
+    save("context_projector", seed=4, **outs)
+
+
 def main():
     assert _refimport.available(), "the reference is not mounted; fixtures can only be generated in the build container"
     os.makedirs(OUT, exist_ok=True)
@@ -299,7 +322,7 @@ def main():
     only = sys.argv[1:]
     gens = {"unipc": lambda: gen_unipc(ns), "masks": gen_masks, "text_weight": gen_text_weight, "dit_tiny": lambda: gen_dit_tiny(ns),
             "sampler": lambda: gen_sampler(ns), "vae": lambda: gen_vae(ns), "block": lambda: gen_dit_block_3072(ns),
-            "siglip2": gen_siglip2}
+            "siglip2": gen_siglip2, "projector": gen_projector}
     for k, fn in gens.items():
         if not only or k in only:
             fn()

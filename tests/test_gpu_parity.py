@@ -1090,3 +1090,37 @@ def test_fp16_operand_kernels():
         L().flash_attn(q, k, vt, out, Lq, Lk, H, D, 1.0 / math.sqrt(D))
         err = (out.double() - truth).abs()
         assert (err <= 3 * ulp16(truth.float()).double() + 5e-4 * truth.abs().max()).all(), f"f16 attention: {float(err.max()):.3e}"
+
+
+def test_context_projector_vs_reference_golden():
+    """univid_amd.model_pipeline.ContextProjector (HIP) against the outputs of the reference's own class (model_pipeline.py:1506-
+    1574, bf16 module): token counts equal to / below / above the target length (linear resampling of the token axis)."""
+    import types
+    from oracle import projector
+    from univid_amd.model_pipeline import ContextProjector
+    g = load_golden("context_projector")
+    cfg = types.SimpleNamespace(bagel_hidden_dim=128, wan_text_dim=256, wan_text_length=32, use_semantic_alignment=False)
+    m = ContextProjector(cfg)
+    m.load_state_dict(projector.make_state_dict(128, 256, int(g["seed"])))
+    m = m.to(DEV).eval()
+    for L in (32, 20, 77):
+        outs = m(g[f"tokens_{L}"])
+        assert len(outs) == 2 and all(o.shape == (32, 256) and o.dtype == BF16 for o in outs)
+        got, ref = torch.stack(outs).float().cpu(), g[f"out_{L}"].float()
+        d = (got - ref).abs()
+        rel_rms = float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        # six bf16-rounded stages (Linear, LayerNorm, GELU, Linear, LayerNorm, resampling): a one-ulp flip early on moves a
+        # LayerNorm row by a few ulps, so the gate is rms error + a bound in ulps of the OUTPUT RANGE + the bit-identical share
+        assert rel_rms < 1.5e-3 and float(d.max()) <= 4 * float(bf16_ulp(ref.abs().max())), f"L={L}: rel rms {rel_rms:.2e}, max {float(d.max()):.2e}"
+        if L == 32:
+            assert (d == 0).float().mean() > 0.9, f"only {float((d == 0).float().mean()):.4f} bit-identical"
+        else:
+            # the resampling kernel alone: bit-exact against F.interpolate on the same bf16 rows
+            cfg.wan_text_length = L
+            pre = torch.stack(m(g[f"tokens_{L}"])).cpu()
+            cfg.wan_text_length = 32
+            want = torch.nn.functional.interpolate(pre.transpose(1, 2), size=32, mode="linear", align_corners=False).transpose(1, 2)
+            assert torch.equal(torch.stack(outs).cpu(), want), f"L={L} interpolation"
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(g["tokens_32"])

@@ -145,3 +145,12 @@ def test_siglip2_oracle_matches_transformers_golden():
     assert idx == g["rank_idx"].tolist() and torch.allclose(torch.tensor(vals), g["rank_vals"].float(), atol=1e-6)
     for K, lam, key in ((5, 0.5, "mmr_5_05"), (12, 0.2, "mmr_12_02"), (20, 0.9, "mmr_20_09")):
         assert siglip2.mmr_select(g["mmr_embs"], g["mmr_query"], K, lam) == g[key].tolist()
+
+
+def test_context_projector_oracle_matches_reference_golden():
+    from oracle import projector
+    g = load_golden("context_projector")
+    sd = projector.make_state_dict(128, 256, int(g["seed"]))
+    for L in (32, 20, 77):
+        out = torch.stack(projector.forward(sd, g[f"tokens_{L}"], 32))
+        assert out.dtype == torch.bfloat16 and torch.equal(out, g[f"out_{L}"])

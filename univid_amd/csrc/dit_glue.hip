@@ -526,3 +526,53 @@ extern "C" int uv_l2_normalize_rows_f32(const float* x, long ldx, float* out, lo
     UV_CHECK_LAUNCH("uv_l2_normalize_rows_f32");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// ContextProjector glue (models/model_pipeline.py:1506-1574, bf16 module):
+//   uv_gelu_erf_bf16          nn.GELU() (exact, erf) on a bf16 tensor: f32 evaluation, one rounding
+//   uv_interp_linear_rows_bf16 F.interpolate(x^T, size=Lout, mode='linear', align_corners=False)^T on [Lin, C] bf16 rows:
+//                             src = (i + 0.5) * Lin / Lout - 0.5 (clamped at 0), out = (1-w) x[i0] + w x[min(i0+1, Lin-1)] in f32
+// ------------------------------------------------------------------------------------------------
+__global__ void gelu_erf_bf16_kernel(const bf16_t* in, bf16_t* out, long n) {
+    for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 2; i + 1 < n + 1; i += (long)gridDim.x * blockDim.x * 2) {
+        if (i + 1 < n) {
+            const uint32_t v = *(const uint32_t*)(in + i);
+            const float a = bf2f((bf16_t)(v & 0xffff)), b = bf2f((bf16_t)(v >> 16));
+            const float ga = 0.5f * a * (1.0f + erff(a * 0.70710678118654752440f));
+            const float gb = 0.5f * b * (1.0f + erff(b * 0.70710678118654752440f));
+            *(uint32_t*)(out + i) = pack_bf2(ga, gb);
+        } else if (i < n) {
+            const float a = bf2f(in[i]);
+            out[i] = f2bf(0.5f * a * (1.0f + erff(a * 0.70710678118654752440f)));
+        }
+    }
+}
+
+extern "C" int uv_gelu_erf_bf16(const void* in, void* out, long n, void* stream) {
+    UV_CHECK_ARG(in && out && n > 0 && (((uintptr_t)in | (uintptr_t)out) & 3) == 0, "uv_gelu_erf_bf16: bad arguments");
+    const int blocks = (int)min((n / 2 + 255) / 256 + 1, (long)4096);
+    hipLaunchKernelGGL(gelu_erf_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, n);
+    UV_CHECK_LAUNCH("uv_gelu_erf_bf16");
+    return 0;
+}
+
+__global__ void interp_linear_rows_bf16_kernel(const bf16_t* in, long ldi, bf16_t* out, long ldo, int Lin, int Lout, int C) {
+    const int row = blockIdx.x;
+    const float scale = (float)Lin / (float)Lout;
+    float src = scale * ((float)row + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    const int i0 = (int)src;
+    const int i1 = i0 + (i0 < Lin - 1 ? 1 : 0);
+    const float w1 = src - (float)i0, w0 = 1.0f - w1;
+    const bf16_t* a = in + (long)i0 * ldi;
+    const bf16_t* b = in + (long)i1 * ldi;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[(long)row * ldo + c] = f2bf(w0 * bf2f(a[c]) + w1 * bf2f(b[c]));
+}
+
+extern "C" int uv_interp_linear_rows_bf16(const void* in, long ldi, void* out, long ldo, int Lin, int Lout, int C, void* stream) {
+    UV_CHECK_ARG(in && out && Lin > 0 && Lout > 0 && C > 0, "uv_interp_linear_rows_bf16: bad arguments");
+    hipLaunchKernelGGL(interp_linear_rows_bf16_kernel, dim3(Lout), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ldi,
+                       (bf16_t*)out, ldo, Lin, Lout, C);
+    UV_CHECK_LAUNCH("uv_interp_linear_rows_bf16");
+    return 0;
+}

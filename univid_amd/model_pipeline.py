@@ -184,6 +184,62 @@ class Wan22ContextWrapper:
             del self.sampling_step_counter
 
 
+class ContextProjector(torch.nn.Module):
+    """BAGEL semantic tokens [B, L, 3584] -> list of Wan text-context tensors [512, 4096] (models/model_pipeline.py:1506-1574):
+    Linear(3584 -> 8192) -> LayerNorm -> GELU (exact) -> Dropout (identity in eval) -> Linear(8192 -> 4096) -> LayerNorm, all in
+    bf16 (`.to(dtype=GLOBAL_TARGET_DTYPE)`), then linear interpolation of the token axis to `wan_text_length`.
+
+    Same module tree (`bagel_to_t5_projector.{0,1,4,5}`), so a trained projector's state dict (`training_state.pt
+    ['context_projector']`, inference.py:227-236) loads unchanged. Compute: `uv_gemm_bf16_nt` (bias, bf16-rounded fp32 out),
+    `uv_layernorm_mod` (affine, bf16 out), `uv_gelu_erf_bf16`, `uv_interp_linear_rows_bf16`."""
+
+    def __init__(self, config):
+        super().__init__()
+        nn = torch.nn
+        self.config = config
+        self.bagel_dim, self.wan_text_dim = config.bagel_hidden_dim, config.wan_text_dim
+        self.bagel_to_t5_projector = nn.Sequential(
+            nn.Linear(self.bagel_dim, self.wan_text_dim * 2), nn.LayerNorm(self.wan_text_dim * 2), nn.GELU(), nn.Dropout(0.1),
+            nn.Linear(self.wan_text_dim * 2, self.wan_text_dim), nn.LayerNorm(self.wan_text_dim)).to(dtype=torch.bfloat16)
+
+    @torch.no_grad()
+    def forward(self, bagel_tokens: torch.Tensor):
+        from . import _lib
+        from ._lib import EPI_F32_FROM_BF16
+        if self.training:
+            raise NotImplementedError("the HIP ContextProjector is inference-only (Dropout is the identity)")
+        seq = self.bagel_to_t5_projector
+        l1, n1, l2, n2 = seq[0], seq[1], seq[4], seq[5]
+        dev = l1.weight.device
+        B, L, _ = bagel_tokens.shape
+        bf = torch.bfloat16
+        out = []
+        for b in range(B):
+            x = bagel_tokens[b].to(device=dev, dtype=bf).contiguous()
+            K1 = (x.shape[1] + 63) // 64 * 64
+            w1 = l1.weight.detach()
+            if K1 != x.shape[1]:      # the GEMM's K granularity is 64: zero-pad the operand columns
+                x = torch.nn.functional.pad(x, (0, K1 - x.shape[1]))
+                w1 = torch.nn.functional.pad(w1, (0, K1 - w1.shape[1]))
+            h1 = torch.empty(L, w1.shape[0], dtype=torch.float32, device=dev)
+            _lib.gemm_bf16(x, w1.contiguous(), l1.bias.detach(), h1, EPI_F32_FROM_BF16)        # bf16 Linear output, held as fp32
+            y1 = torch.empty(L, w1.shape[0], dtype=bf, device=dev)
+            _lib.layernorm_mod(h1, y1, L, w1.shape[0], n1.eps, mode=2, w=n1.weight.detach().float(), b=n1.bias.detach().float())
+            _lib.call("uv_gelu_erf_bf16", _lib.ptr(y1), _lib.ptr(y1), y1.numel(), _lib.stream_ptr())
+            h2 = torch.empty(L, l2.weight.shape[0], dtype=torch.float32, device=dev)
+            _lib.gemm_bf16(y1, l2.weight.detach(), l2.bias.detach(), h2, EPI_F32_FROM_BF16)
+            y2 = torch.empty(L, l2.weight.shape[0], dtype=bf, device=dev)
+            _lib.layernorm_mod(h2, y2, L, l2.weight.shape[0], n2.eps, mode=2, w=n2.weight.detach().float(), b=n2.bias.detach().float())
+            T = self.config.wan_text_length
+            if L != T:
+                z = torch.empty(T, y2.shape[1], dtype=bf, device=dev)
+                _lib.call("uv_interp_linear_rows_bf16", _lib.ptr(y2), y2.stride(0), _lib.ptr(z), z.stride(0), L, T, y2.shape[1],
+                          _lib.stream_ptr())
+                y2 = z
+            out.append(y2)
+        return out
+
+
 class CrossAttentionFusionPipeline:
     """model_pipeline.py:2110-3230, inference side. Components are injected:
 
