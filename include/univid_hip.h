@@ -69,6 +69,13 @@ int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const v
 int uv_flash_attn_f16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                       int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream);
 
+/* umT5 text-encoder attention (models/wan/utils/modules/t5.py:93-120), one prompt of n <= 1024 tokens, head_dim 64, bf16:
+ * scores = bf16(bf16(q k^T) + rel_bias[h][key - query]) (no scaling), P = bf16(softmax_fp32(scores)), out = bf16(P v) - the
+ * reference's rounding points. q, k, v, out [n, H*64]; rel_bias fp32 [H, 2*span - 1] (bf16 values of T5RelativeEmbedding for
+ * relative positions -(span-1) .. span-1), span >= n. */
+int uv_t5_attention_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out, long ldo, int n, int H,
+                         const float* rel_bias, int span, void* stream);
+
 /* ---- DiT: fused HBM-bound glue ------------------------------------------------------------------------------ */
 /* LayerNorm(no affine) over C then mode 0: y | 1: y*(1+scale[t])+shift[t] (t = tid[row]) | 2: y*w+b.
  * Replaces WanLayerNorm + AdaLN modulation (model.py:93-98, 239-245, 253, 287-290). round_ln=1 rounds y to bf16 first
@@ -111,6 +118,11 @@ int uv_l2_normalize_rows_f32(const float* x, long ldx, float* out, long ldo, int
  * and F.interpolate(mode='linear', align_corners=False) along the token axis of [Lin, C] bf16 rows. */
 int uv_gelu_erf_bf16(const void* in, void* out, long n, void* stream);
 int uv_interp_linear_rows_bf16(const void* in, long ldi, void* out, long ldo, int Lin, int Lout, int C, void* stream);
+
+/* umT5 encoder glue (t5.py, bf16 module): bf16 residual add (:175-176); fc1 * GELU(gate) with the reference's op-by-op bf16 GELU
+ * (:46-50, :138). */
+int uv_add_bf16(const void* x, const void* y, void* out, long n, void* stream);
+int uv_t5_gated_gelu_bf16(const void* gate, const void* fc1, void* out, long n, void* stream);
 
 /* ---- sampler (CFG + flow UniPC order 2 / bh2 / predict-x0) -------------------------------------------------- */
 /* noise_pred = uncond + gs*(cond - uncond) (textimage2video.py:385); x0 = sample - sigma*noise_pred

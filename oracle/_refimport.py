@@ -215,3 +215,32 @@ def ref_context_projector(config):
     exec(compile(ast.Module(body=[cls], type_ignores=[]), "model_pipeline.py:ContextProjector", "exec"), ns)
     with contextlib.redirect_stdout(io.StringIO()):
         return ns["ContextProjector"](config)
+
+
+def ref_t5_encoder(cfg):
+    """The reference's T5Encoder (models/wan/utils/modules/t5.py:267-312) built from its file with a stub for the sibling
+    `tokenizers` module (which needs ftfy / regex data not in this image)."""
+    import importlib.util
+    import sys
+    import types
+    pkg = "uvref_t5pkg"
+    if pkg not in sys.modules:
+        mod_pkg = types.ModuleType(pkg)
+        mod_pkg.__path__ = [_MODDIR]
+        sys.modules[pkg] = mod_pkg
+        tok = types.ModuleType(pkg + ".tokenizers")
+        tok.HuggingfaceTokenizer = object
+        sys.modules[pkg + ".tokenizers"] = tok
+        spec = importlib.util.spec_from_file_location(pkg + ".t5", os.path.join(_MODDIR, "t5.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[pkg + ".t5"] = m
+        real = torch.cuda.current_device          # t5.py:479 evaluates torch.cuda.current_device() in a default argument
+        torch.cuda.current_device = lambda: 0
+        try:
+            spec.loader.exec_module(m)
+        finally:
+            torch.cuda.current_device = real
+    t5 = sys.modules[pkg + ".t5"]
+    return t5.T5Encoder(vocab=cfg["vocab_size"], dim=cfg["dim"], dim_attn=cfg["dim_attn"], dim_ffn=cfg["dim_ffn"],
+                        num_heads=cfg["num_heads"], num_layers=cfg["num_layers"], num_buckets=cfg["num_buckets"], shared_pos=False,
+                        dropout=0.1)

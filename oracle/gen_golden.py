@@ -19,7 +19,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import _refimport, projector, sampler, siglip2, unipc, wan_dit, wan_vae  # noqa: E402
+from oracle import _refimport, projector, sampler, siglip2, t5, unipc, wan_dit, wan_vae  # noqa: E402
 from univid_amd import detinit  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -314,6 +314,30 @@ def gen_projector():
     save("context_projector", seed=4, **outs)
 
 
+def gen_t5():
+    """umT5 encoder (t5.py:267-312) at reduced size: the reference module in bf16 on padded ids + mask, sliced to the prompt length."""
+    print("t5 encoder")
+    cfg = t5.TINY_CFG
+    ref = _refimport.ref_t5_encoder(cfg).to(torch.bfloat16).eval()
+    sd = t5.make_state_dict(cfg, seed=9)
+    ref.load_state_dict(sd)
+    g = torch.Generator().manual_seed(12)
+    T = 48
+    outs = {}
+    for n in (48, 33, 5):
+        ids = torch.zeros(1, T, dtype=torch.long)
+        ids[0, :n] = torch.randint(1, cfg["vocab_size"], (n,), generator=g)
+        mask = (torch.arange(T) < n).long().unsqueeze(0)
+        with torch.no_grad():
+            r = ref(ids, mask)[0, :n]
+        o = t5.encode(sd, cfg, ids[0, :n])
+        assert torch.equal(r, o), (n, float((r.float() - o.float()).abs().max()))
+        outs[f"ids_{n}"] = ids[0, :n]
+        outs[f"out_{n}"] = r
+    rel = torch.arange(-200, 201)
+    save("t5_tiny", seed=9, rel=rel, buckets=t5.relative_position_bucket(rel), **outs)
+
+
 def main():
     assert _refimport.available(), "the reference is not mounted; fixtures can only be generated in the build container"
     os.makedirs(OUT, exist_ok=True)
@@ -322,7 +346,7 @@ def main():
     only = sys.argv[1:]
     gens = {"unipc": lambda: gen_unipc(ns), "masks": gen_masks, "text_weight": gen_text_weight, "dit_tiny": lambda: gen_dit_tiny(ns),
             "sampler": lambda: gen_sampler(ns), "vae": lambda: gen_vae(ns), "block": lambda: gen_dit_block_3072(ns),
-            "siglip2": gen_siglip2, "projector": gen_projector}
+            "siglip2": gen_siglip2, "projector": gen_projector, "t5": gen_t5}
     for k, fn in gens.items():
         if not only or k in only:
             fn()

@@ -1124,3 +1124,33 @@ def test_context_projector_vs_reference_golden():
     m.train()
     with pytest.raises(NotImplementedError):
         m(g["tokens_32"])
+
+
+def test_umt5_encoder_vs_reference_golden():
+    """univid_amd.wan.t5.T5Encoder (HIP) against the reference T5Encoder's bf16 outputs (t5.py:267-312): prompts of 48, 33 and 5
+    tokens (the latter two padded + masked in the reference). The kernels keep the reference's rounding points, so most elements
+    are bit-identical; GEMM accumulation order accounts for the rest."""
+    from oracle import t5 as ot5
+    from univid_amd.wan.t5 import T5Encoder, T5EncoderModel
+    g = load_golden("t5_tiny")
+    cfg = ot5.TINY_CFG
+    m = T5Encoder(vocab=cfg["vocab_size"], dim=cfg["dim"], dim_attn=cfg["dim_attn"], dim_ffn=cfg["dim_ffn"], num_heads=cfg["num_heads"],
+                  num_layers=cfg["num_layers"], num_buckets=cfg["num_buckets"])
+    m.load_state_dict(ot5.make_state_dict(cfg, int(g["seed"])))
+    m = m.to(device=DEV, dtype=BF16).eval()
+    assert torch.equal(m.blocks[0].pos_embedding.bucket(g["rel"].to(DEV)).cpu(), g["buckets"])
+    for n in (48, 33, 5):
+        got, ref = m.encode(g[f"ids_{n}"]).float().cpu(), g[f"out_{n}"].float()
+        d = (got - ref).abs()
+        rel_rms = float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        assert rel_rms < 3e-3 and float(d.max()) <= 6 * float(bf16_ulp(ref.abs().max())), f"n={n}: rel rms {rel_rms:.2e} max {float(d.max()):.2e}"
+        assert (d == 0).float().mean() > 0.8, f"n={n}: only {float((d == 0).float().mean()):.3f} bit-identical"
+    # reference-signature forward and the T5EncoderModel wrapper (tokenizer injected)
+    ids = torch.zeros(2, 48, dtype=torch.long)
+    ids[0, :33], ids[1, :5] = g["ids_33"], g["ids_5"]
+    mask = torch.stack([(torch.arange(48) < 33).long(), (torch.arange(48) < 5).long()])
+    full = m(ids.to(DEV), mask.to(DEV))
+    assert full.shape == (2, 48, cfg["dim"]) and (full[0, 33:] == 0).all() and torch.equal(full[1, :5], m.encode(g["ids_5"]))
+    enc = T5EncoderModel(text_len=48, device=DEV, model=m, tokenizer=lambda texts, **kw: (ids, mask))
+    ctx = enc(["a", "b"], DEV)
+    assert [c.shape[0] for c in ctx] == [33, 5] and torch.equal(ctx[0], full[0, :33])

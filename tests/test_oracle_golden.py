@@ -154,3 +154,13 @@ def test_context_projector_oracle_matches_reference_golden():
     for L in (32, 20, 77):
         out = torch.stack(projector.forward(sd, g[f"tokens_{L}"], 32))
         assert out.dtype == torch.bfloat16 and torch.equal(out, g[f"out_{L}"])
+
+
+def test_t5_oracle_matches_reference_golden():
+    """oracle/t5.py against the outputs of the reference's own T5Encoder (bf16, padded ids + mask, sliced to the prompt)."""
+    from oracle import t5
+    g = load_golden("t5_tiny")
+    sd = t5.make_state_dict(t5.TINY_CFG, int(g["seed"]))
+    for n in (48, 33, 5):
+        assert torch.equal(t5.encode(sd, t5.TINY_CFG, g[f"ids_{n}"]), g[f"out_{n}"])
+    assert torch.equal(t5.relative_position_bucket(g["rel"]), g["buckets"])

@@ -27,6 +27,9 @@ SIGNATURES = {
     "uv_flash_attn_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "uv_flash_attn_f16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "uv_layernorm_mod": [_P, _L, _P, _L, _I, _I, _F, _I, _P, _L, _I, _I, _P, _P, _P, _I, _I, _P],
+    "uv_t5_attention_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _I, _P],
+    "uv_add_bf16": [_P, _P, _P, _L, _P],
+    "uv_t5_gated_gelu_bf16": [_P, _P, _P, _L, _P],
     "uv_gelu_erf_bf16": [_P, _P, _L, _P],
     "uv_interp_linear_rows_bf16": [_P, _L, _P, _L, _I, _I, _I, _P],
     "uv_l2_normalize_rows_f32": [_P, _L, _P, _L, _I, _I, _F, _P],

@@ -576,3 +576,45 @@ extern "C" int uv_interp_linear_rows_bf16(const void* in, long ldi, void* out, l
     UV_CHECK_LAUNCH("uv_interp_linear_rows_bf16");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// umT5 encoder glue (models/wan/utils/modules/t5.py, bf16 module: every torch op on a bf16 tensor computes in fp32 and rounds once)
+//   uv_add_bf16            out = bf16(x + y)                                  residual adds, t5.py:175-176
+//   uv_t5_gated_gelu_bf16  out = bf16(fc1 * GELU(gate)) with the reference's op-by-op GELU (t5.py:46-50, 138):
+//                          0.5 * x * (1.0 + tanh(sqrt(2/pi) * (x + 0.044715 * pow(x, 3)))), each op rounded to bf16
+// ------------------------------------------------------------------------------------------------
+__global__ void add_bf16_kernel(const bf16_t* x, const bf16_t* y, bf16_t* out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = f2bf(bf2f(x[i]) + bf2f(y[i]));
+}
+
+extern "C" int uv_add_bf16(const void* x, const void* y, void* out, long n, void* stream) {
+    UV_CHECK_ARG(x && y && out && n > 0, "uv_add_bf16: bad arguments");
+    hipLaunchKernelGGL(add_bf16_kernel, dim3((int)min((n + 255) / 256, (long)4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)out, n);
+    UV_CHECK_LAUNCH("uv_add_bf16");
+    return 0;
+}
+
+__global__ void t5_gated_gelu_bf16_kernel(const bf16_t* gate, const bf16_t* fc1, bf16_t* out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float x = bf2f(gate[i]);
+        const float t1 = round_bf(round_bf(x * x) * x);                     // torch.pow(x, 3.0) on a bf16 tensor = (x * x) * x, each product rounded
+        const float t2 = round_bf(0.044715f * t1);
+        const float t3 = round_bf(x + t2);
+        const float t4 = round_bf(0.7978845608028654f * t3);
+        const float t5 = round_bf(tanhf(t4));
+        const float t6 = round_bf(1.0f + t5);
+        const float t7 = round_bf(0.5f * x);
+        const float g = round_bf(t7 * t6);
+        out[i] = f2bf(bf2f(fc1[i]) * g);
+    }
+}
+
+extern "C" int uv_t5_gated_gelu_bf16(const void* gate, const void* fc1, void* out, long n, void* stream) {
+    UV_CHECK_ARG(gate && fc1 && out && n > 0, "uv_t5_gated_gelu_bf16: bad arguments");
+    hipLaunchKernelGGL(t5_gated_gelu_bf16_kernel, dim3((int)min((n + 255) / 256, (long)4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)gate, (const bf16_t*)fc1, (bf16_t*)out, n);
+    UV_CHECK_LAUNCH("uv_t5_gated_gelu_bf16");
+    return 0;
+}
