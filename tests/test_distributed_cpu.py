@@ -112,3 +112,39 @@ def test_sequence_parallel_exchanges(world, L):
     for p in procs:
         p.join(30)
     assert all(ok for _, ok in res), res
+
+
+def _cfgp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if world != 2:
+            try:
+                parallel.CfgParallel()
+                q.put((rank, False))
+            except ValueError:
+                q.put((rank, True))
+            return
+        cp = parallel.CfgParallel()
+        mine = torch.full((3, 2, 4), float(rank + 1))
+        cond, uncond = cp.exchange(mine)
+        ok = cp.branch == ("cond", "uncond")[rank] and torch.equal(cond, torch.full((3, 2, 4), 1.0)) and torch.equal(uncond, torch.full((3, 2, 4), 2.0))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cfg_parallel_exchange(world):
+    """A CFG pair is exactly two ranks: rank 0 holds the conditional prediction, rank 1 the unconditional one, both get both."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cfgp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(ok for _, ok in res), res

@@ -875,6 +875,49 @@ def test_sequence_parallel_forward_is_bit_identical(world):
     assert all(ok and refused for _, ok, refused, _ in res), res
 
 
+def _cfgp_gpu_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+        g = load_golden("sampler_tiny")
+        cfg, sd, m = _tiny_model(g["seed"])
+        pipe = WanTI2V(TI2VConfig, model=m, device=DEV)
+        args = (g["noise"].to(DEV), [g["ctx"].to(DEV)], [g["ctx_null"].to(DEV)], 4, g["shift"], g["guide_scale"])
+        with torch.no_grad():
+            plain = pipe.denoise(*args)
+            plain_i2v = pipe.denoise(*args, z=g["z"].to(DEV))
+            pipe.enable_cfg_parallel()
+            rec = []
+            split = pipe.denoise(*args, record=rec)
+            split_i2v = pipe.denoise(*args, z=g["z"].to(DEV))
+        ok = torch.equal(split, plain) and torch.equal(split_i2v, plain_i2v) and len(rec) == 4
+        q.put((rank, bool(ok), pipe.cfgp.branch, float((split - plain).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg_parallel_denoise_is_bit_identical():
+    """SURVEY 8(e) intra-sample sharding: cond on rank 0, uncond on rank 1, one all-gather of the prediction per step; both ranks
+    must end every step with the latent of the single-process loop, bit for bit (t2v and i2v). Two processes on the one GPU, gloo."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cfgp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _, _ in res), res
+    assert [b for _, _, b, _ in res] == ["cond", "uncond"]
+
+
 def _sp_full_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

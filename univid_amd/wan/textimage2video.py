@@ -96,6 +96,7 @@ class WanTI2V:
         self.vae_stride = config.vae_stride
         self.patch_size = config.patch_size
         self.sp_size = 1
+        self.cfgp = None
         self.sample_neg_prompt = config.sample_neg_prompt
         self.text_encoder = text_encoder
         self.vae = vae
@@ -110,6 +111,13 @@ class WanTI2V:
             # runs the same sample (same seed) and holds the full result after each forward
             self.model.enable_sequence_parallel()
             self.sp_size = self.model.sp.size
+
+    def enable_cfg_parallel(self, group=None):
+        """Extension: the ranks of `group` (exactly 2) split the cond / uncond forwards of every step and exchange
+        the predictions with one all-gather; all ranks must pass the same inputs (same seed) and end with the same latent."""
+        from ..parallel import CfgParallel
+        self.cfgp = CfgParallel(group)
+        return self
 
     # ---- prompt embeds ---------------------------------------------------------------------------------------
     def _encode(self, prompt, embeds):
@@ -159,7 +167,13 @@ class WanTI2V:
             temp_ts = base_mask * ts                                                   # :373
             temp_ts = torch.cat([temp_ts, temp_ts.new_ones(seq_len - temp_ts.size(0)) * ts])
             tvec = temp_ts.unsqueeze(0)
-            if "forward" in self.model.__dict__:
+            if self.cfgp is not None:
+                if "forward" in self.model.__dict__:
+                    raise NotImplementedError("the per-forward text-weight counter (model_pipeline.py:1856-1868) counts two forwards "
+                                              "per step on one rank; it cannot be combined with CFG parallelism")
+                mine = context if self.cfgp.rank == 0 else context_null
+                cond, uncond = self.cfgp.exchange(self.model([latent], t=tvec, context=mine, seq_len=seq_len)[0])
+            elif "forward" in self.model.__dict__:
                 # model.forward was re-assigned (UniVid's per-forward text-weight counter, model_pipeline.py:1856-1868):
                 # keep the reference's two calls so the counter advances exactly as there
                 cond = self.model([latent], t=tvec, context=context, seq_len=seq_len)[0]
