@@ -649,6 +649,302 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Three-waves-per-SIMD form (head_dim 128, bf16): same arithmetic, tile order and rounding points as the default kernel
+// above - the results are bit-identical - but sized so that THREE 4-wave workgroups fit a CU:
+//   * LDS 48 KiB per workgroup: K double-buffered, V^T single-buffered. V^T(t) is requested at the top of tile t (its buffer
+//     is free once every wave has left tile t-1) and is needed only after QK(t) + softmax(t); K(t+1) is requested right
+//     behind it. Two barriers per tile (V^T landed / tile done); with three independent workgroups per CU a parked wave
+//     costs nothing as long as one of the other two has work for the SIMD.
+//   * <= 168 registers per wave: the LDS-DMA sources are ONE uniform (SGPR) base pointer per operand, advanced once per
+//     tile, plus a constant 32-bit lane offset per piece (the default kernel carries 8 running 64-bit pointers and the
+//     clamped-row state of the ragged tile); the ragged tile recomputes its clamped addresses from the lane id.
+// A lone wave needs ~3 440 cycles per tile of which 1 024 are MFMA issue; two waves per SIMD overlap almost perfectly
+// (3 500 cycles per PAIR of tiles), i.e. the chain is latency- not throughput-bound and a third wave has room.
+// ------------------------------------------------------------------------------------------------------------------------
+// One LDS-DMA piece with a UNIFORM base pointer (SGPR pair) and a 32-bit lane offset: "global_load_lds_dwordx4 voff, s[base]".
+// hipcc selects only the 64-bit-VGPR-address form for the builtin (one v_lshl_add_u64 and a live register pair per piece).
+// M0 = wave-uniform LDS byte address of the piece; saved and restored around the statement (the compiler owns M0).
+__device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+// AHEAD = fragment reads in flight ahead of their MFMA; KPL = where the K(t+1) pieces are issued (0 after QK of half 0, 1 after PV of
+// half 0); PRIO = raise the wave priority over the MFMA clusters.
+template <int AHEAD = 3, int KPL = 0, int PRIO = 0, bool XCD = true>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void flash_attn_fwd3_kernel(AttnArgs p) {
+    constexpr int D = 128, NW = 4, KROW = 256, NKK = 8, ND = 4;
+    constexpr int K_BYTES = UV_ATT_KV * KROW, V_BYTES = D * 128;
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_BYTES + V_BYTES];
+    constexpr int V_OFF = 2 * K_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2. In plain (sample, head)-
+    // major order the ~96 workgroups resident on an XCD span 8-9 heads, so every L2 streams the K / V^T of 8-9 heads at once and
+    // each head's K / V^T is pulled into all 8 L2s. Remapped, XCD x works through the contiguous range [x NB/8, (x+1) NB/8) of
+    // (sample, head, q-block) ids: one or two heads at a time per L2, each head in one L2 only.
+    int vb = blockIdx.x;
+    if constexpr (XCD) {
+        const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
+        const int x = vb & 7, j = vb >> 3;
+        // XCD x owns per + (x < rem) ids; its range starts after the ranges of XCDs 0 .. x-1
+        vb = x * per + min(x, rem) + j;
+    }
+    const int bh = vb / p.q_blocks;
+    const int qb = vb - bh * p.q_blocks;
+    const int head = bh % p.H;
+    {
+        const long b = bh / p.H;
+        p.q += b * p.Lq * p.ldq;
+        p.k += b * p.Lk * p.ldk;
+        p.vt += (long)b * p.Lk;
+        p.out += b * p.Lq * p.ldo;
+    }
+    const int q0w = qb * (NW * UV_ATT_QW) + wave_u * UV_ATT_QW;
+    const long hcol = (long)head * D;
+
+    bf16x8 qf[NKK];
+    {
+        const int qrow = min(q0w + r, p.Lq - 1);
+        const bf16_t* qp = p.q + (long)qrow * p.ldq + hcol + 8 * h;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
+    }
+
+    // LDS-DMA pieces of this wave: 4 of K (4 rows of 256 B each), 4 of V^T (8 rows of 128 B each); see the default kernel for
+    // the row permutation and the swizzles. Piece i of a wave covers LDS rows 16 i further on (K) / 32 i (V^T); neither the
+    // swizzle key nor the row permutation sees those bits, so ONE lane offset per operand serves all four pieces and the
+    // piece stride goes into the uniform base. Offsets in BYTES relative to the tile's first key row / key column.
+    unsigned koff, voff;
+    {
+        const int lrow = wave_u * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ (lrow & 15);
+        koff = (unsigned)(perm23(lrow) * (int)p.ldk + c * 8) * 2u;
+        const int drow = wave_u * 8 + (lane >> 3);
+        const int cv = (lane & 7) ^ ((drow >> 1) & 7);
+        voff = (unsigned)(drow * (int)p.ldvt + cv * 8) * 2u;
+    }
+    const char* kbase = (const char*)(p.k + hcol);                       // tile 0; += kstep per tile
+    const char* vbase = (const char*)(p.vt + hcol * p.ldvt);             // tile 0; += 128 B per tile
+    const long kstep = (long)UV_ATT_KV * p.ldk * 2;
+    const long kpiece = 16 * p.ldk * 2, vpiece = 32 * p.ldvt * 2;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_a*)smem + wave_u * 1024;   // this wave's first piece in buffer 0
+    auto fetch_k_full = [&](const char* base_t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_sbase(base_t + i * kpiece, koff, lds0 + buf * K_BYTES + i * NW * 1024);
+    };
+    auto fetch_k_clamped = [&](int kv0, int buf) {                       // the ragged last tile (and a lone short tile 0)
+        char* dst = smem + buf * K_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int lrow = (i * NW + wave_u) * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (lrow & 15);
+            const int kr = min(kv0 + perm23(lrow), p.Lk - 1);
+            const bf16_t* src = p.k + hcol + (long)kr * p.ldk + c * 8;
+            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(dst + (i * NW + wave_u) * 1024), 16, 0, 0);
+        }
+    };
+    auto fetch_v = [&](const char* base_t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_sbase(base_t + i * vpiece, voff, lds0 + V_OFF + i * NW * 1024);
+    };
+
+    // fragment read addresses (LDS byte offsets from smem; buffer / key-half / d-tile offsets are instruction immediates)
+    typedef const __attribute__((address_space(3))) bf16x8* lds_frag_p;
+    const unsigned smem_a = (unsigned)(uintptr_t)(lds_void_a*)smem;
+    unsigned kaddr[NKK];
+    unsigned vaddr[2][2];
+    {
+        const int k_key = r & 15, v_key = (r >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) kaddr[kk] = smem_a + r * KROW + (((2 * kk + h) ^ k_key) << 4);
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) vaddr[T][s2] = smem_a + V_OFF + r * 128 + (((4 * T + 2 * s2 + h) ^ v_key) << 4);
+    }
+
+    f32x16 oacc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (p.Lk + UV_ATT_KV - 1) / UV_ATT_KV;
+    const int nt_full = p.Lk / UV_ATT_KV;
+    if (nt_full > 0) fetch_k_full(kbase, 0);
+    else fetch_k_clamped(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]), "+v"(kaddr[kk]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(vaddr[i >> 1][i & 1]));
+    asm volatile("" : "+v"(koff), "+v"(voff));
+    __syncthreads();
+
+    // One staged tile = 64 keys = two 32-key halves that are computed one after the other (QK, softmax, PV per half): the S
+    // accumulator of only one half is live beside O and Q, which is what leaves registers for fragment reads ahead of their
+    // MFMAs at 168 registers per wave. The reference maximum is therefore reconsidered per half.
+    // NEXT: 1 = tile t+1 is a full one, 0 = decide at run time (ragged or none); PAR = t & 1 (compile-time: the K buffer
+    // offsets become instruction immediates)
+    auto tile = [&](int t, auto masked_tag, auto next_tag, auto par_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool NEXT_FULL = decltype(next_tag)::value;
+        constexpr int PAR = decltype(par_tag)::value;
+        const int kv0 = t * UV_ATT_KV;
+        fetch_v(vbase);                                  // V^T(t): the buffer was released by the barrier that ended tile t-1
+        vbase += 2 * UV_ATT_KV;
+        kbase += kstep;
+        bool k_pending = true;
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            f32x16 sacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const bf16x8 kf = *(lds_frag_p)(kaddr[kk] + PAR * K_BYTES + T * 32 * KROW);
+                sacc = mfma_32x32x16<false>(kf, qf[kk], sacc);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);      // fragment reads AHEAD ahead of their MFMAs
+#pragma unroll
+            for (int i_ = 0; i_ < 8 - AHEAD; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (T == 0 && KPL == 0) {
+                // K(t+1) into the other K buffer (every wave left tile t-1, its last reader, before the barrier that opened tile t)
+                if constexpr (NEXT_FULL) {
+                    fetch_k_full(kbase, PAR ^ 1);
+                } else {
+                    if (t + 1 < nt_full) fetch_k_full(kbase, PAR ^ 1);
+                    else if (t + 1 < nt) fetch_k_clamped(kv0 + UV_ATT_KV, PAR ^ 1);
+                    else k_pending = false;
+                }
+            }
+            if (MASKED) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (kv0 + perm23(i) >= p.Lk) sacc[e] = -INFINITY;
+                }
+            }
+            float mt = sacc[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mt = fmaxf(mt, sacc[e]);
+            {
+                const unsigned u = __builtin_bit_cast(unsigned, mt);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                mt = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+            }
+            const float grow = (mt - m_run) * p.scale_log2;
+            if (__any(grow > UV_ATT_DEFER)) {
+                const float m_new = fmaxf(m_run, mt);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+                m_run = m_new;
+            }
+            const float mneg = -m_run * p.scale_log2;
+            float psum = 0.f;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[8 * s2 + j], p.scale_log2, mneg));
+                    psum += pv;
+                    pf[s2][j] = (__bf16)pv;
+                }
+            l_run += psum;
+            if (T == 0) {
+                // V^T(t) of every wave has landed: the K(t+1) pieces were issued after it and may stay in flight
+                if (k_pending && KPL == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 vf = *(lds_frag_p)(vaddr[T][s2] + d * 32 * 128);
+                    oacc[d] = mfma_32x32x16<false>(vf, pf[s2], oacc[d]);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 1);
+#pragma unroll
+            for (int i_ = 0; i_ < 8 - AHEAD; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            if (T == 0 && KPL == 1) {
+                if constexpr (NEXT_FULL) {
+                    fetch_k_full(kbase, PAR ^ 1);
+                } else {
+                    if (t + 1 < nt_full) fetch_k_full(kbase, PAR ^ 1);
+                    else if (t + 1 < nt) fetch_k_clamped(kv0 + UV_ATT_KV, PAR ^ 1);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's share of K(t+1); own LDS reads retired
+        __builtin_amdgcn_s_barrier();
+    };
+
+    using F = std::false_type;
+    using T_ = std::true_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 2 < nt_full; t += 2) {
+        tile(t, F{}, T_{}, P0{});
+        tile(t + 1, F{}, T_{}, P1{});
+    }
+    // 0, 1 or 2 full tiles left (t is even)
+    if (t + 1 < nt_full) {
+        tile(t, F{}, T_{}, P0{});
+        tile(t + 1, F{}, F{}, P1{});
+    } else if (t < nt_full) {
+        tile(t, F{}, F{}, P0{});
+    }
+    if (nt_full < nt) {
+        if (nt_full & 1) tile(nt_full, T_{}, F{}, P1{});
+        else tile(nt_full, T_{}, F{}, P0{});
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0w + r;
+    if (q < p.Lq) {
+        bf16_t* op = p.out + (long)q * p.ldo + hcol + 4 * h;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o = {pack16_2<false>(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv),
+                           pack16_2<false>(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv)};
+                *(u32x2*)(op + 32 * d + 8 * g) = o;
+            }
+    }
+}
+
 extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
                                   void* out, long ldo, int batch, int Lq, int Lk, int H, int head_dim,
                                   float softmax_scale, void* stream) {
@@ -684,6 +980,16 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
         a.q_blocks = (Lq + 255) / 256;
         if (qb2 == 2) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, false, 2, true>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a, nostamps);
         else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, false, 2, false>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a, nostamps);
+        UV_CHECK_LAUNCH("uv_flash_attn_bf16");
+        return 0;
+    }
+    static int w3 = -1;
+    if (w3 < 0) { const char* e = getenv("UV_ATTN_W3"); w3 = e ? atoi(e) : 1; }   // A/B knob: 0 = the two-waves-per-SIMD kernel
+    if (w3 && head_dim == 128 && 128 * ldvt < (1L << 30) && 64 * ldk < (1L << 30)) {   // 32-bit lane offsets of the LDS-DMA pieces
+        a.q_blocks = (Lq + 127) / 128;
+        const dim3 g3(a.q_blocks * H * batch), b3(256);
+        if (w3 == 2) hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, 0, 0, false>), g3, b3, 0, st, a);   // A/B: plain block order
+        else hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, 0, 0, true>), g3, b3, 0, st, a);
         UV_CHECK_LAUNCH("uv_flash_attn_bf16");
         return 0;
     }
