@@ -234,6 +234,30 @@ def test_flash_attention_vs_oracle(Lq, Lk, H, D):
     assert e_hip.pow(2).mean().sqrt() <= 1.5 * e_ora.pow(2).mean().sqrt() + 1e-5
 
 
+@pytest.mark.parametrize("Lk", [5, 63, 64, 65, 128, 129, 192, 200, 256, 321])
+def test_flash_attention_key_tile_edges(Lk):
+    """Every path of the key-tile loop of the head_dim-128 kernel (two-tile unrolled main loop with compile-time buffer parity, one or two
+    peeled full tiles, the ragged tile on either buffer, a lone short tile): against the fp64 softmax, with ragged query rows (Lq = 150:
+    the second workgroup's last wave owns no query) and V = 1 giving exactly 1."""
+    Lq, H, D = 150, 2, 128
+    C = H * D
+    g = torch.Generator().manual_seed(100 + Lk)
+    q, k, v = (torch.randn(n, C, generator=g).to(BF16) for n in (Lq, Lk, Lk))
+    qf, kf, vf = (t.double().view(-1, H, D).transpose(0, 1) for t in (q, k, v))
+    truth = (torch.softmax(qf @ kf.transpose(1, 2) / math.sqrt(D), -1) @ vf).transpose(0, 1).reshape(Lq, C)
+    vt = torch.zeros(C, (Lk + 63) // 64 * 64, dtype=BF16, device=DEV)
+    vt[:, :Lk] = v.t().to(DEV)
+    out = torch.full((Lq + 8, C), 7.0, dtype=BF16, device=DEV)      # guard rows: nothing may be written past Lq
+    L().flash_attn(q.to(DEV), k.to(DEV), vt, out, Lq, Lk, H, D, 1.0 / math.sqrt(D))
+    assert (out[Lq:] == 7.0).all()
+    err = (out[:Lq].double().cpu() - truth).abs()
+    assert (err <= 3 * bf16_ulp(truth.float()) + 2e-3 * float(truth.abs().max())).all(), f"Lk={Lk}: max err {float(err.max()):.3e}"
+    vt[:, :Lk] = 1.0
+    vt[:, Lk:] = 1000.0                                              # padding columns must never be attended
+    L().flash_attn(q.to(DEV), k.to(DEV), vt, out, Lq, Lk, H, D, 1.0 / math.sqrt(D))
+    assert (out[:Lq].float() - 1).abs().max() <= 2 ** -7
+
+
 @pytest.mark.parametrize("spike", [4.0, 0.45, 0.2])
 def test_flash_attention_rescale_branch_and_rowsum(spike):
     """A key that dominates late: spike 4 moves the softmax reference maximum (the rescale branch of the online softmax),
