@@ -135,6 +135,8 @@ def main():
                     "(26 PFLOP per step: use --steps 1 --warmup 1; not the metric)")
     ap.add_argument("--sp", action="store_true", help="N > 1: Ulysses sequence parallelism (ONE sample's tokens sharded over the "
                     "ranks, strong scaling) instead of the default one-sample-per-GPU replicas")
+    ap.add_argument("--cfg-parallel", action="store_true", help="N = 2: the cond / uncond forwards of ONE sample on the two ranks, one "
+                    "all-gather of the prediction per step (strong scaling; not the metric's replica mode)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,7 +168,14 @@ def main():
     use_sp = bool(args.sp and world > 1)
     if use_sp:
         model.enable_sequence_parallel()
-    g = torch.Generator(device=device).manual_seed(42 + (0 if use_sp else rank))   # SP: every rank holds the same sample
+    cfgp = None
+    if args.cfg_parallel:
+        if world != 2 or use_sp:
+            raise SystemExit("--cfg-parallel needs exactly 2 ranks and excludes --sp")
+        from univid_amd.parallel import CfgParallel
+        cfgp = CfgParallel()
+    shared = use_sp or cfgp is not None
+    g = torch.Generator(device=device).manual_seed(42 + (0 if shared else rank))   # SP / CFG pair: every rank holds the same sample
     latent = torch.randn(*LATENT, device=device, generator=g)
     ctx = [torch.randn(77, cfg["text_dim"], device=device, generator=g) * 0.1]
     ctx_null = [torch.randn(12, cfg["text_dim"], device=device, generator=g) * 0.1]
@@ -180,7 +189,10 @@ def main():
         t = timesteps[i]
         tvec = torch.full((1, seq_len), float(t), device=device)
         # exactly what WanTI2V.denoise does per timestep: the CFG pair as one stacked pass (bit-identical per sample)
-        cond, uncond = model([lat, lat], t=torch.cat([tvec, tvec]), context=[ctx[0], ctx_null[0]], seq_len=seq_len)
+        if cfgp is not None:
+            cond, uncond = cfgp.exchange(model([lat], t=tvec, context=[ctx[0] if cfgp.rank == 0 else ctx_null[0]], seq_len=seq_len)[0])
+        else:
+            cond, uncond = model([lat, lat], t=torch.cat([tvec, tvec]), context=[ctx[0], ctx_null[0]], seq_len=seq_len)
         return sched.step_cfg(cond.unsqueeze(0), uncond.unsqueeze(0), GUIDE, t, lat.unsqueeze(0)).squeeze(0)
 
     def barrier():
@@ -198,7 +210,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
             latent = one_step(i, latent)
-        if world > 1 and not use_sp:  # the single collective of the path: final latents to every rank (8.8 MB/GPU)
+        if world > 1 and not shared:  # the single collective of the path: final latents to every rank (8.8 MB/GPU)
             gathered = [torch.empty_like(latent) for _ in range(world)]
             dist.all_gather(gathered, latent)
         barrier()
@@ -242,14 +254,14 @@ def main():
                         "flops_per_launch": launch_flops}
         step_flops = 2 * dit_forward_flops(L_TOKENS, cfg)
         out = {
-            "metric": "denoise_steps_per_sec", "value": round((1 if use_sp else world) * args.steps / dt_max, 4), "unit": "steps/s",
+            "metric": "denoise_steps_per_sec", "value": round((1 if shared else world) * args.steps / dt_max, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong" if use_sp else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if shared else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("49-frame 704x1280 latent [48,13,44,80], L=11440 tokens" if args.shape == "A" else
                                     "STRESS SHAPE (not the metric): literal 49x90x160 latent [48,49,90,160], L=176400 tokens") +
                                    "; TI2V-5B DiT (dim 3072, ffn 14336, 24 heads, %d layers); 1 step = cond+uncond forward + CFG + UniPC; "
                                    "one sample per GPU" % cfg["num_layers"],
-                       "samples_per_gpu": 1, "guide_scale": GUIDE, "shift": SHIFT, "parallelism": (f"ulysses sequence parallel x{world}, 4 all-to-alls per block" if use_sp else f"replicas x{world}, all-gather of final latents")},
+                       "samples_per_gpu": 1, "guide_scale": GUIDE, "shift": SHIFT, "parallelism": (f"ulysses sequence parallel x{world}, 4 all-to-alls per block" if use_sp else "cfg pair x2, one all-gather of the prediction per step" if cfgp is not None else f"replicas x{world}, all-gather of final latents")},
             "step_tflop": round(step_flops / 1e12, 1),
             "model_tflops_per_gpu": round(step_flops * args.steps / dt_max / 1e12, 1),
             "mfma_frac_whole_step": round(step_flops * args.steps / dt_max / 1e12 / PEAK_BF16_TFLOPS, 4),
