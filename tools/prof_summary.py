@@ -33,6 +33,12 @@ def stats(path):
             continue
         print(f"| `{short(name)}` | {g} x {w} | {len(v)} | {sum(v) / 1e6:.2f} | {sum(v) / len(v) / 1e3:.1f} | {min(v) / 1e3:.1f} | "
               f"{max(v) / 1e3:.1f} | {100 * sum(v) / total:.2f} |")
+    # the attention kernel serves self-attention (Lk = L) and cross-attention (Lk = 512) under one name: split by duration
+    att = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if "flash_attn" in r["Kernel_Name"]]
+    big, small = [x for x in att if x > 1e6], [x for x in att if x <= 1e6]
+    if big and small:
+        print(f"\nattention dispatches split by use: self-attention {len(big)} launches, avg {sum(big) / len(big) / 1e3:.1f} us "
+              f"(min {min(big) / 1e3:.1f}, max {max(big) / 1e3:.1f}); cross-attention {len(small)} launches, avg {sum(small) / len(small) / 1e3:.1f} us")
 
 
 def pmc(fetch_path, write_path):
