@@ -673,9 +673,8 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
                  : "memory");
 }
 
-// AHEAD = fragment reads in flight ahead of their MFMA; KPL = where the K(t+1) pieces are issued (0 after QK of half 0, 1 after PV of
-// half 0); PRIO = raise the wave priority over the MFMA clusters.
-template <int AHEAD = 3, int KPL = 0, int PRIO = 0, bool XCD = true>
+// AHEAD = fragment reads in flight ahead of their MFMA (2 .. 5 measured: all within 0.5 %); XCD = XCD-aware block order (A/B knob).
+template <int AHEAD = 3, bool XCD = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void flash_attn_fwd3_kernel(AttnArgs p) {
     constexpr int D = 128, NW = 4, KROW = 256, NKK = 8, ND = 4;
     constexpr int K_BYTES = UV_ATT_KV * KROW, V_BYTES = D * 128;
@@ -823,7 +822,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
             __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (T == 0 && KPL == 0) {
+            if (T == 0) {
                 // K(t+1) into the other K buffer (every wave left tile t-1, its last reader, before the barrier that opened tile t)
                 if constexpr (NEXT_FULL) {
                     fetch_k_full(kbase, PAR ^ 1);
@@ -873,11 +872,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             l_run += psum;
             if (T == 0) {
                 // V^T(t) of every wave has landed: the K(t+1) pieces were issued after it and may stay in flight
-                if (k_pending && KPL == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (k_pending) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int d = 0; d < ND; ++d)
@@ -894,15 +892,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
             __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-            if (T == 0 && KPL == 1) {
-                if constexpr (NEXT_FULL) {
-                    fetch_k_full(kbase, PAR ^ 1);
-                } else {
-                    if (t + 1 < nt_full) fetch_k_full(kbase, PAR ^ 1);
-                    else if (t + 1 < nt) fetch_k_clamped(kv0 + UV_ATT_KV, PAR ^ 1);
-                }
-            }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's share of K(t+1); own LDS reads retired
         __builtin_amdgcn_s_barrier();
@@ -988,8 +977,8 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
     if (w3 && head_dim == 128 && 128 * ldvt < (1L << 30) && 64 * ldk < (1L << 30)) {   // 32-bit lane offsets of the LDS-DMA pieces
         a.q_blocks = (Lq + 127) / 128;
         const dim3 g3(a.q_blocks * H * batch), b3(256);
-        if (w3 == 2) hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, 0, 0, false>), g3, b3, 0, st, a);   // A/B: plain block order
-        else hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, 0, 0, true>), g3, b3, 0, st, a);
+        if (w3 == 2) hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, false>), g3, b3, 0, st, a);   // A/B: plain block order
+        else hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, true>), g3, b3, 0, st, a);
         UV_CHECK_LAUNCH("uv_flash_attn_bf16");
         return 0;
     }
