@@ -212,3 +212,27 @@ def test_siglip2_state_dict_is_hf_compatible():
     assert mine == {k: tuple(v) for k, v in osl.state_dict_shapes(osl.TINY_CFG).items()}
     with pytest.raises(NotImplementedError):
         Siglip2Model(dict(vision=dict(osl.TINY_CFG["vision"], hidden_size=192, num_attention_heads=3), text=osl.TINY_CFG["text"]))
+
+
+def test_tokenizer_wrapper_cleaning_and_padding(tmp_path):
+    """univid_amd.wan.tokenizers.HuggingfaceTokenizer (reference tokenizers.py:38-82): cleaning modes, padding / truncation to seq_len,
+    the (ids, mask) pair T5EncoderModel consumes. The tokenizer files are a tiny word-level vocabulary built here."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    from univid_amd.wan.tokenizers import HuggingfaceTokenizer, clean_text
+    assert clean_text("  a &amp;amp; b\n\n c  ", "whitespace") == "a & b c"
+    assert clean_text(" Hello   World ", "lower") == "hello world"
+    assert clean_text("A_cat, sitting! (on) a_mat.", "canonicalize") == "a cat sitting on a mat"
+    assert clean_text("  keep  me ", None) == "  keep  me "
+    with pytest.raises(ValueError):
+        clean_text("x", "shout")
+    vocab = {"<pad>": 0, "</s>": 1, "<unk>": 2, "a": 3, "cat": 4, "on": 5, "mat": 6, "&": 7}
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    PreTrainedTokenizerFast(tokenizer_object=tok, pad_token="<pad>", eos_token="</s>", unk_token="<unk>").save_pretrained(tmp_path)
+    t = HuggingfaceTokenizer(str(tmp_path), seq_len=6, clean="whitespace")
+    ids, mask = t(["a   cat  on a mat on a mat", "cat &amp; dog"], return_mask=True, add_special_tokens=True)
+    assert ids.shape == (2, 6) and mask.shape == (2, 6)
+    assert ids[0].tolist() == [3, 4, 5, 3, 6, 5] and mask[0].tolist() == [1] * 6          # truncated to seq_len
+    assert ids[1].tolist() == [4, 7, 2, 0, 0, 0] and mask[1].tolist() == [1, 1, 1, 0, 0, 0]  # cleaned, unknown word, padded
+    assert t("a cat").shape == (1, 6) and t.vocab_size == len(vocab)

@@ -168,8 +168,9 @@ def umt5_xxl_encoder(**kw):
 
 
 class T5EncoderModel:
-    """t5.py:473-513. The tokenizer (HuggingfaceTokenizer: text -> (ids [B, text_len], mask)) is injected; pass model= to reuse an
-    encoder, or checkpoint_path= to load `models_t5_umt5-xxl-enc-bf16.pth`."""
+    """t5.py:473-513: tokenizer_path= builds the HuggingfaceTokenizer (whitespace cleaning, padded / truncated to text_len) as the
+    reference does, or inject tokenizer=; pass model= to reuse an encoder, or checkpoint_path= to load
+    `models_t5_umt5-xxl-enc-bf16.pth`."""
 
     def __init__(self, text_len, dtype=torch.bfloat16, device="cuda", checkpoint_path=None, tokenizer_path=None, shard_fn=None, *,
                  tokenizer=None, model: T5Encoder = None):
@@ -185,8 +186,11 @@ class T5EncoderModel:
                 model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"))
         self.model = model.to(device=self.device, dtype=dtype).eval().requires_grad_(False)
         if tokenizer is None:
-            raise ValueError("pass tokenizer= (texts -> (ids [B, text_len], mask [B, text_len])); the reference's HuggingfaceTokenizer "
-                             f"for {tokenizer_path!r} needs the `tokenizers` data files")
+            if tokenizer_path is None:
+                raise ValueError("pass tokenizer_path= (a Hugging Face tokenizer directory, e.g. google/umt5-xxl) or tokenizer= "
+                                 "(texts -> (ids [B, text_len], mask [B, text_len]))")
+            from .tokenizers import HuggingfaceTokenizer
+            tokenizer = HuggingfaceTokenizer(name=tokenizer_path, seq_len=text_len, clean="whitespace")   # t5.py:509-510
         self.tokenizer = tokenizer
 
     def __call__(self, texts, device=None):
