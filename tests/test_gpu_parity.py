@@ -1221,3 +1221,58 @@ def test_umt5_encoder_vs_reference_golden():
     enc = T5EncoderModel(text_len=48, device=DEV, model=m, tokenizer=lambda texts, **kw: (ids, mask))
     ctx = enc(["a", "b"], DEV)
     assert [c.shape[0] for c in ctx] == [33, 5] and torch.equal(ctx[0], full[0, :33])
+
+
+def test_pipeline_composes_native_text_encoder_projector_dit():
+    """CrossAttentionFusionPipeline.generate_video_with_bagel_context (model_pipeline.py:2577-2655) with every stage native: prompt ->
+    tokenizer (injected) -> umT5 encoder on HIP -> contexts; BAGEL tokens (stub extractor) -> ContextProjector on HIP; tiny DiT + UniPC
+    loop with the per-layer text-weight hook. The result must equal the same loop driven with the encoder's embeddings passed in
+    directly, be deterministic, and differ from the run without the dynamic text weight."""
+    import types
+    from oracle import projector, t5 as ot5
+    from univid_amd.model_pipeline import ContextProjector, CrossAttentionConfig, CrossAttentionFusionPipeline
+    from univid_amd.wan.t5 import T5Encoder, T5EncoderModel
+    from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+    g5 = load_golden("t5_tiny")
+    tcfg = ot5.TINY_CFG
+    enc_m = T5Encoder(vocab=tcfg["vocab_size"], dim=tcfg["dim"], dim_attn=tcfg["dim_attn"], dim_ffn=tcfg["dim_ffn"], num_heads=tcfg["num_heads"],
+                      num_layers=tcfg["num_layers"], num_buckets=tcfg["num_buckets"])
+    enc_m.load_state_dict(ot5.make_state_dict(tcfg, int(g5["seed"])))
+    prompts = {"a cat": g5["ids_33"], "": g5["ids_5"]}
+
+    def tokenizer(texts, **kw):
+        ids = torch.zeros(len(texts), 48, dtype=torch.long)
+        mask = torch.zeros(len(texts), 48, dtype=torch.long)
+        for i, t in enumerate(texts):
+            n = prompts[t].numel()
+            ids[i, :n], mask[i, :n] = prompts[t], 1
+        return ids, mask
+
+    enc = T5EncoderModel(text_len=48, device=DEV, model=enc_m, tokenizer=tokenizer)
+    cfg, sd, m = _tiny_model(load_golden("dit_tiny")["seed"], text_dim=tcfg["dim"], text_len=48)
+    pipe = WanTI2V(TI2VConfig, model=m, device=DEV, text_encoder=enc)
+    pipe.sample_neg_prompt = ""
+    pcfg = types.SimpleNamespace(bagel_hidden_dim=128, wan_text_dim=tcfg["dim"], wan_text_length=32, use_semantic_alignment=False)
+    proj = ContextProjector(pcfg)
+    proj.load_state_dict(projector.make_state_dict(128, tcfg["dim"], 3))
+    proj = proj.to(DEV).eval()
+    bagel = types.SimpleNamespace(extract_semantic_tokens=lambda text, image: torch.randn(1, 20, 128, generator=torch.Generator().manual_seed(1)))
+    ccfg = CrossAttentionConfig(total_sampling_steps=3, text_weight_transition_ratio=0.7, use_dynamic_text_weight=True, bagel_sequence_length=16)
+    fusion = CrossAttentionFusionPipeline(ccfg, wan_pipeline=pipe, bagel_extractor=bagel, context_projector=proj)
+    kw = dict(steps=3, guidance_scale=5.0, frames=13, size=(256, 256), shift=5.0, seed=11, decode=False)
+    with torch.no_grad():
+        lat, path = fusion.generate_video_with_bagel_context("a cat", **kw)
+        lat2, _ = fusion.generate_video_with_bagel_context("a cat", **kw)
+        emb, emb_n = enc(["a cat"], DEV), enc([""], DEV)
+        lat3, _ = fusion.generate_video_with_bagel_context("ignored", prompt_embeds=emb, negative_prompt_embeds=emb_n, **kw)
+    assert path is None and lat.shape == (48, 4, 16, 16) and torch.isfinite(lat).all()
+    assert torch.equal(lat, lat2) and torch.equal(lat, lat3)
+    assert emb[0].shape == (33, tcfg["dim"]) and emb_n[0].shape == (5, tcfg["dim"])
+    assert fusion.get_fusion_info()["hooked_layers"] == cfg["num_layers"] and not fusion.wan_wrapper.use_bagel_context
+    fusion.cleanup_resources()
+    plain = CrossAttentionFusionPipeline(CrossAttentionConfig(total_sampling_steps=3, use_dynamic_text_weight=False), wan_pipeline=pipe,
+                                         bagel_extractor=bagel, context_projector=proj)
+    with torch.no_grad():
+        lat4, _ = plain.generate_video_with_bagel_context("a cat", **kw)
+    assert torch.isfinite(lat4).all() and not torch.equal(lat, lat4)
+    plain.cleanup_resources()
