@@ -29,6 +29,10 @@ SHAPES = [
     ("tail strip K=14336", 1120, 3072, 14336, EPI_GATE_RESID_F32),
     ("o-shape, f32 write only", L2, 3072, 3072, EPI_F32_FROM_BF16),
     ("o-shape, f32 resid", L2, 3072, 3072, EPI_RESID_F32),
+    ("8192^3", 8192, 8192, 8192, EPI_BF16),
+    ("aligned q (89 x 256 rows)", 22784, 3072, 3072, EPI_BF16),
+    ("aligned ffn.0 shape", 22784, 14336, 3072, EPI_BF16),
+    ("aligned ffn.2 shape", 22784, 3072, 14336, EPI_BF16),
 ]
 
 
