@@ -120,7 +120,7 @@ class T5Encoder(nn.Module):
         n, d, H = ids.shape[0], self.dim, self.num_heads
         wf = self._norm_weights()
         x = self.token_embedding.weight.detach()[ids].contiguous()
-        span = max(n, 8)
+        span = _round_up(n, 512)      # one bias table per layer serves every prompt length up to text_len
         for li, blk in enumerate(self.blocks):
             key = (li, span)
             if key not in self._tabs:
