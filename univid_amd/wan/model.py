@@ -321,9 +321,10 @@ _zero_cache = {}
 
 
 def _zeros_cached(key, shape, dtype, device):
-    """Zero-initialised scratch whose padding region is never written (V^T column padding)."""
+    """Zero-initialised scratch whose padding region is never written (V^T column padding). One tensor per key: a new shape
+    replaces the old one (the caching allocator frees it in stream order), so the cache does not grow with the resolutions served."""
     t = _zero_cache.get(key)
-    if t is None:
+    if t is None or tuple(t.shape) != tuple(shape):
         t = torch.zeros(shape, dtype=dtype, device=device)
         _zero_cache[key] = t
     return t
@@ -335,7 +336,7 @@ def _vt_scratch(tag, C, batch, L, device):
         raise NotImplementedError(f"stacked samples need a token count divisible by 8 (got {L}); run them one by one")
     cols = (batch - 1) * L + _round_up(L, 64)
     # one scratch per stream: forwards running concurrently on different streams must not share it
-    return _zeros_cached((tag, C, cols, device, torch.cuda.current_stream(device).cuda_stream), (C, cols), BF16, device)
+    return _zeros_cached((tag, device, torch.cuda.current_stream(device).cuda_stream), (C, cols), BF16, device)
 
 
 def _ensure_prepared(mod):
