@@ -247,7 +247,7 @@ def main():
                 pass
             if args.shape != "A":
                 traffic = None    # the PMC passes were taken at shape A
-            roofline = {"kernel": f"flash_attn_fwd3_kernel (self-attention, cond+uncond batch 2 x Lq=Lk={L_TOKENS}, 24 heads)", "bound": "mfma",
+            roofline = {"kernel": f"flash_attn_fwd12_kernel (self-attention, cond+uncond batch 2 x Lq=Lk={L_TOKENS}, 24 heads)", "bound": "mfma",
                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(self_ev),

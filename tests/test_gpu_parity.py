@@ -258,6 +258,39 @@ def test_flash_attention_key_tile_edges(Lk):
     assert (out[:Lq].float() - 1).abs().max() <= 2 ** -7
 
 
+@pytest.mark.parametrize("Lk", [2048, 2104, 2112, 2184])
+def test_flash_attention_long_key_kernel(Lk):
+    """Lk >= 2048 selects the 12-wave-workgroup kernel (384 queries per workgroup, K / V^T tiles shared by 12 waves): even / odd tile
+    counts, ragged last tile, a ragged last workgroup (Lq = 500), two stacked samples; against the fp64 softmax on sampled rows, the
+    stacked launch bit-identical to the single ones, V = 1 -> exactly 1, nothing written past Lq."""
+    Lq, H, D, B = 500, 2, 128, 2
+    C = H * D
+    g = torch.Generator(device=DEV).manual_seed(Lk)
+    q = torch.randn(B * Lq, C, generator=g, device=DEV).to(BF16)
+    k = torch.randn(B * Lk, C, generator=g, device=DEV).to(BF16)
+    v = torch.randn(B * Lk, C, generator=g, device=DEV).to(BF16)
+    cols = (B - 1) * Lk + (Lk + 63) // 64 * 64
+    vt = torch.zeros(C, cols, dtype=BF16, device=DEV)
+    vt[:, :B * Lk] = v.t()
+    out = torch.full((B * Lq + 8, C), 7.0, dtype=BF16, device=DEV)
+    L().flash_attn(q, k, vt, out, Lq, Lk, H, D, D ** -0.5, batch=B)
+    assert (out[B * Lq:] == 7.0).all()
+    for b in range(B):
+        qs, ks, vs = (t[b * n:(b + 1) * n].double().view(n, H, D).transpose(0, 1) for t, n in ((q, Lq), (k, Lk), (v, Lk)))
+        truth = (torch.softmax(qs @ ks.transpose(1, 2) / math.sqrt(D), -1) @ vs).transpose(0, 1).reshape(Lq, C)
+        err = (out[b * Lq:(b + 1) * Lq].double() - truth).abs()
+        assert (err <= 3 * bf16_ulp(truth.float()) + 2e-3 * float(truth.abs().max())).all(), f"sample {b}: max err {float(err.max()):.3e}"
+        vt1 = torch.zeros(C, (Lk + 63) // 64 * 64, dtype=BF16, device=DEV)
+        vt1[:, :Lk] = v[b * Lk:(b + 1) * Lk].t()
+        o1 = torch.zeros(Lq, C, dtype=BF16, device=DEV)
+        L().flash_attn(q[b * Lq:(b + 1) * Lq], k[b * Lk:(b + 1) * Lk], vt1, o1, Lq, Lk, H, D, D ** -0.5)
+        assert torch.equal(out[b * Lq:(b + 1) * Lq], o1), f"sample {b}: stacked != single"
+    ones = torch.ones(C, (Lk + 63) // 64 * 64, dtype=BF16, device=DEV)
+    ones[:, Lk:] = 1000.0
+    L().flash_attn(q[:Lq], k[:Lk], ones, out, Lq, Lk, H, D, D ** -0.5)
+    assert (out[:Lq].float() - 1).abs().max() <= 2 ** -7
+
+
 @pytest.mark.parametrize("spike", [4.0, 0.45, 0.2])
 def test_flash_attention_rescale_branch_and_rowsum(spike):
     """A key that dominates late: spike 4 moves the softmax reference maximum (the rescale branch of the online softmax),

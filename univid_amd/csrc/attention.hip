@@ -934,6 +934,252 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Long key sequences (default for Lk >= 2048; UV_ATTN_W3=1 keeps the 4-wave form): ONE 12-wave workgroup per CU (384 queries, three
+// waves per SIMD) sharing each K / V^T tile: a third of the L2 -> LDS traffic and 2-3 instead of 8 LDS-DMA pieces per wave and tile.
+// Bit-identical to flash_attn_fwd3_kernel (same per-wave arithmetic). Removing its barrier (timing probe) gains 0.6 %. Staging as in the two-waves kernel (K and
+// V^T double-buffered, tile t+1 requested at the top of tile t, ONE vmcnt(0) + barrier per tile), compute body and register
+// diet of flash_attn_fwd3_kernel (32-key halves, SGPR-base DMA, immediates for the buffer parity).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int AHEAD = 3, bool XCD = true>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void flash_attn_fwd12_kernel(AttnArgs p) {
+    constexpr int D = 128, NW = 12, KROW = 256, NKK = 8, ND = 4;
+    constexpr int K_BYTES = UV_ATT_KV * KROW, V_BYTES = D * 128;
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_BYTES + 2 * V_BYTES];
+    constexpr int V_OFF = 2 * K_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int vb = blockIdx.x;
+    if constexpr (XCD) {
+        const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
+        const int x = vb & 7, j = vb >> 3;
+        vb = x * per + min(x, rem) + j;
+    }
+    const int bh = vb / p.q_blocks;
+    const int qb = vb - bh * p.q_blocks;
+    const int head = bh % p.H;
+    {
+        const long b = bh / p.H;
+        p.q += b * p.Lq * p.ldq;
+        p.k += b * p.Lk * p.ldk;
+        p.vt += (long)b * p.Lk;
+        p.out += b * p.Lq * p.ldo;
+    }
+    const int q0w = qb * (NW * UV_ATT_QW) + wave_u * UV_ATT_QW;
+    const long hcol = (long)head * D;
+
+    bf16x8 qf[NKK];
+    {
+        const int qrow = min(q0w + r, p.Lq - 1);
+        const bf16_t* qp = p.q + (long)qrow * p.ldq + hcol + 8 * h;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
+    }
+
+    // The 32 pieces of a tile (K pieces 0..15 = 4 LDS rows each, V^T pieces 0..15 = 8 rows each) are dealt round-robin: wave w
+    // issues K piece w, K piece w + 12 (w < 4), V^T piece w - 4 (w >= 4) and V^T piece w + 8 (w < 8). Pieces 12 apart (K) / of equal
+    // parity (V^T) share the swizzle key and the row permutation bits, so one lane offset per operand serves both.
+    const int s4 = lane >> 4, s8 = lane >> 3;
+    unsigned koff, voff;
+    {
+        const int p3 = wave_u & 3;
+        const int c = (lane & 15) ^ ((4 * p3 + s4) & 15);
+        const int swap2 = ((p3 & 1) << 1) | (p3 >> 1);
+        koff = (unsigned)((s4 + 4 * swap2) * (int)p.ldk + c * 8) * 2u;
+        const int cv = (lane & 7) ^ ((4 * (wave_u & 1) + (s8 >> 1)) & 7);
+        voff = (unsigned)(s8 * (int)p.ldvt + cv * 8) * 2u;
+    }
+    const char* kbase = (const char*)(p.k + hcol);
+    const char* vbase = (const char*)(p.vt + hcol * p.ldvt);
+    const long kstep = (long)UV_ATT_KV * p.ldk * 2;
+    const long k16 = 16 * p.ldk * 2, v8 = 8 * p.ldvt * 2;
+    const unsigned smem_a = (unsigned)(uintptr_t)(lds_void_a*)smem;
+    const int kp0 = wave_u, kp1 = wave_u + 12;                // K pieces (kp1 only for wave < 4)
+    const int vq0 = wave_u - 4, vq1 = wave_u + 8;             // V^T pieces (vq0 for wave >= 4, vq1 for wave < 8)
+    auto fetch_full = [&](const char* kb_t, const char* vb_t, int buf) {
+        glds16_sbase(kb_t + (kp0 >> 2) * k16, koff, smem_a + buf * K_BYTES + kp0 * 1024);
+        if (wave_u < 4) glds16_sbase(kb_t + (kp1 >> 2) * k16, koff, smem_a + buf * K_BYTES + kp1 * 1024);
+        if (wave_u >= 4) glds16_sbase(vb_t + vq0 * v8, voff, smem_a + V_OFF + buf * V_BYTES + vq0 * 1024);
+        if (wave_u < 8) glds16_sbase(vb_t + vq1 * v8, voff, smem_a + V_OFF + buf * V_BYTES + vq1 * 1024);
+    };
+    auto fetch_clamped = [&](int kv0, const char* vb_t, int buf) {      // ragged last tile / lone short tile: clamped K rows
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int pc = w ? kp1 : kp0;
+            if (pc < 16) {
+                const int lrow = 4 * pc + s4;
+                const int c = (lane & 15) ^ (lrow & 15);
+                const int kr = min(kv0 + perm23(lrow), p.Lk - 1);
+                const bf16_t* src = p.k + hcol + (long)kr * p.ldk + c * 8;
+                __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(smem + buf * K_BYTES + pc * 1024), 16, 0, 0);
+            }
+        }
+        if (wave_u >= 4) glds16_sbase(vb_t + vq0 * v8, voff, smem_a + V_OFF + buf * V_BYTES + vq0 * 1024);
+        if (wave_u < 8) glds16_sbase(vb_t + vq1 * v8, voff, smem_a + V_OFF + buf * V_BYTES + vq1 * 1024);
+    };
+
+    typedef const __attribute__((address_space(3))) bf16x8* lds_frag_p;
+    unsigned kaddr[NKK];
+    unsigned vaddr[2][2];
+    {
+        const int k_key = r & 15, v_key = (r >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) kaddr[kk] = smem_a + r * KROW + (((2 * kk + h) ^ k_key) << 4);
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) vaddr[T][s2] = smem_a + V_OFF + r * 128 + (((4 * T + 2 * s2 + h) ^ v_key) << 4);
+    }
+
+    f32x16 oacc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (p.Lk + UV_ATT_KV - 1) / UV_ATT_KV;
+    const int nt_full = p.Lk / UV_ATT_KV;
+    if (nt_full > 0) fetch_full(kbase, vbase, 0);
+    else fetch_clamped(0, vbase, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]), "+v"(kaddr[kk]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(vaddr[i >> 1][i & 1]));
+    asm volatile("" : "+v"(koff), "+v"(voff));
+    __syncthreads();
+
+    auto tile = [&](int t, auto masked_tag, auto next_tag, auto par_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool NEXT_FULL = decltype(next_tag)::value;
+        constexpr int PAR = decltype(par_tag)::value;
+        const int kv0 = t * UV_ATT_KV;
+        vbase += 2 * UV_ATT_KV;
+        kbase += kstep;
+        if constexpr (NEXT_FULL) {
+            fetch_full(kbase, vbase, PAR ^ 1);
+        } else {
+            if (t + 1 < nt_full) fetch_full(kbase, vbase, PAR ^ 1);
+            else if (t + 1 < nt) fetch_clamped(kv0 + UV_ATT_KV, vbase, PAR ^ 1);
+        }
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            f32x16 sacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const bf16x8 kf = *(lds_frag_p)(kaddr[kk] + PAR * K_BYTES + T * 32 * KROW);
+                sacc = mfma_32x32x16<false>(kf, qf[kk], sacc);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+            for (int i_ = 0; i_ < 8 - AHEAD; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MASKED) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (kv0 + perm23(i) >= p.Lk) sacc[e] = -INFINITY;
+                }
+            }
+            float mt = sacc[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mt = fmaxf(mt, sacc[e]);
+            {
+                const unsigned u = __builtin_bit_cast(unsigned, mt);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                mt = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+            }
+            const float grow = (mt - m_run) * p.scale_log2;
+            if (__any(grow > UV_ATT_DEFER)) {
+                const float m_new = fmaxf(m_run, mt);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+                m_run = m_new;
+            }
+            const float mneg = -m_run * p.scale_log2;
+            float psum = 0.f;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[8 * s2 + j], p.scale_log2, mneg));
+                    psum += pv;
+                    pf[s2][j] = (__bf16)pv;
+                }
+            l_run += psum;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 vf = *(lds_frag_p)(vaddr[T][s2] + PAR * V_BYTES + d * 32 * 128);
+                    oacc[d] = mfma_32x32x16<false>(vf, pf[s2], oacc[d]);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 1);
+#pragma unroll
+            for (int i_ = 0; i_ < 8 - AHEAD; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    using F = std::false_type;
+    using T_ = std::true_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 2 < nt_full; t += 2) {
+        tile(t, F{}, T_{}, P0{});
+        tile(t + 1, F{}, T_{}, P1{});
+    }
+    if (t + 1 < nt_full) {
+        tile(t, F{}, T_{}, P0{});
+        tile(t + 1, F{}, F{}, P1{});
+    } else if (t < nt_full) {
+        tile(t, F{}, F{}, P0{});
+    }
+    if (nt_full < nt) {
+        if (nt_full & 1) tile(nt_full, T_{}, F{}, P1{});
+        else tile(nt_full, T_{}, F{}, P0{});
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0w + r;
+    if (q < p.Lq) {
+        bf16_t* op = p.out + (long)q * p.ldo + hcol + 4 * h;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o = {pack16_2<false>(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv),
+                           pack16_2<false>(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv)};
+                *(u32x2*)(op + 32 * d + 8 * g) = o;
+            }
+    }
+}
+
 extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
                                   void* out, long ldo, int batch, int Lq, int Lk, int H, int head_dim,
                                   float softmax_scale, void* stream) {
@@ -973,11 +1219,18 @@ extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long l
         return 0;
     }
     static int w3 = -1;
-    if (w3 < 0) { const char* e = getenv("UV_ATTN_W3"); w3 = e ? atoi(e) : 1; }   // A/B knob: 0 = the two-waves-per-SIMD kernel
+    // A/B knob: 0 = the two-waves-per-SIMD kernel, 1 = three 4-wave workgroups per CU, 3 (default) = one 12-wave workgroup per CU
+    if (w3 < 0) { const char* e = getenv("UV_ATTN_W3"); w3 = e ? atoi(e) : 3; }
     if (w3 && head_dim == 128 && 128 * ldvt < (1L << 30) && 64 * ldk < (1L << 30)) {   // 32-bit lane offsets of the LDS-DMA pieces
         a.q_blocks = (Lq + 127) / 128;
         const dim3 g3(a.q_blocks * H * batch), b3(256);
-        if (w3 == 2) hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, false>), g3, b3, 0, st, a);   // A/B: plain block order
+        if (w3 == 3 && Lk >= 2048) {
+            // long key sequences: one 12-wave workgroup per CU shares each K / V^T tile among 384 queries (a third of the L2 -> LDS
+            // traffic; -2.8 % on the self-attention launches); short ones (cross-attention, Lk = 512: the prologue and the last
+            // round weigh more) keep the 4-wave workgroups (+24 % there otherwise)
+            a.q_blocks = (Lq + 383) / 384;
+            hipLaunchKernelGGL((flash_attn_fwd12_kernel<3, true>), dim3(a.q_blocks * H * batch), dim3(768), 0, st, a);
+        } else if (w3 == 2) hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, false>), g3, b3, 0, st, a);   // A/B: plain block order
         else hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, true>), g3, b3, 0, st, a);
         UV_CHECK_LAUNCH("uv_flash_attn_bf16");
         return 0;
