@@ -6,7 +6,12 @@
 //           q/k/v cast to bf16 :59-83, result cast back :130), called from
 //           WanSelfAttention.forward model.py:145-150 and WanCrossAttention.forward model.py:175.
 //
-// Structure (default: one workgroup = 4 waves = 128 queries of one head, two workgroups per CU; KV tile = 64 keys):
+// Three kernels share the operand layouts, LDS images and arithmetic below:
+//   flash_attn_fwd12_kernel  head_dim 128, bf16, Lk >= 2048 (self-attention): one 12-wave workgroup per CU, 384 queries per K/V^T stream
+//   flash_attn_fwd3_kernel   head_dim 128, bf16, shorter Lk (cross-attention): three 4-wave workgroups per CU (48 KiB LDS, <= 168 registers)
+//   flash_attn_fwd_kernel    head_dim 64 / fp16 operands / very large leading dimensions: two 4-wave workgroups per CU (the first design;
+//                            also carries the QB = 2 one-wave-per-SIMD experiment and the stamped diagnostic build)
+// Common structure (one wave = 32 queries of one head; staged KV tile = 64 keys):
 //   * swapped product S^T = K.Q^T with v_mfma_f32_32x32x16_bf16: the query sits on the lane, its
 //     32 keys of a tile sit in the 16 accumulator registers of both half-waves, so the softmax row
 //     max / sum are register-local plus ONE exchange with lane^32.
