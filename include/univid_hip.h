@@ -22,8 +22,9 @@ extern "C" {
 #endif
 
 /* ---- library ---------------------------------------------------------------------------------------------- */
-int uv_version(void);                      /* 100 = 0.1.0 */
-int uv_init(void);                         /* one-time device allocations; call once per process before use */
+int uv_version(void);                      /* 200 = 0.2.0 */
+const char* uv_build_id(void);             /* digest of the kernel sources the library was built from (loader checks it) */
+int uv_init(void);                         /* one-time allocations for the CURRENT device; call once per device before use */
 const char* uv_last_error(void);           /* thread-local text of the last failure */
 int uv_device_arch(char* buf, int len);    /* e.g. "gfx950:sramecc+:xnack-" */
 
@@ -68,6 +69,15 @@ int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const v
 /* uv_flash_attn_bf16 with IEEE fp16 q / k / vt / out (SigLIP2 ranker: transformers' attention under fp16 autocast). */
 int uv_flash_attn_f16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                       int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream);
+
+/* Operator-seam helpers: what flash_attention(q, k, v, ...) (attention.py:24-130) does around the core when it is handed
+ * [B, L, N, C] tensors of any float dtype: `half(x)` casts (:59-83), and `.type(out_dtype)` of the result (:130); the
+ * transpose produces the V^T operand of uv_flash_attn_* from token-major V rows.
+ * uv_transpose_16: out[c][l] = in[l][c] (16-bit elements, l < L, c < C); columns L .. Lpad-1 are written as zero. */
+int uv_transpose_16(const void* in, long ldi, void* out, long ldo, int L, int C, int Lpad, void* stream);
+/* contiguous f32 -> bf16 (f16 = 0) / IEEE fp16 (f16 = 1), round to nearest even; and the exact widening back */
+int uv_cast_f32_to16(const float* in, void* out, long n, int f16, void* stream);
+int uv_cast_16_to_f32(const void* in, float* out, long n, int f16, void* stream);
 
 /* umT5 text-encoder attention (models/wan/utils/modules/t5.py:93-120), one prompt of n <= 1024 tokens, head_dim 64, bf16:
  * scores = bf16(bf16(q k^T) + rel_bias[h][key - query]) (no scaling), P = bf16(softmax_fp32(scores)), out = bf16(P v) - the

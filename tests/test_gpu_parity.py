@@ -20,7 +20,7 @@ import os
 import pytest
 import torch
 
-from conftest import bf16_ulp, load_golden
+from conftest import bf16_ulp, load_golden, record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -75,18 +75,27 @@ def assert_f32_close(got, ref, rtol=1e-3, atol=1e-4, name=""):
     assert bad == 0, f"{name}: {bad}/{ref.numel()} outside rtol={rtol} atol={atol}; max abs {float((got - ref).abs().max()):.3e}"
 
 
-def assert_model_close(got, ref, truth=None, frac=0.90, name=""):
+def assert_model_close(got, ref, truth=None, frac=0.90, name="", max_rel=1e-2, truth_ratio=1.3):
+    """Composite-path gate; the measured numbers go to the margins file (conftest.record_margin) so `frac`, `max_rel` and
+    `truth_ratio` can be ratcheted against what the driver box measured (profiles/r02_parity_margins.json)."""
     got, ref = got.float().cpu(), ref.float().cpu()
     assert torch.isfinite(got).all(), name
     d = (got - ref).abs()
     inside = (d <= 1e-4 + 1e-3 * ref.abs()).float().mean().item()
-    assert inside >= frac, f"{name}: only {inside:.3f} of elements inside rtol 1e-3 / atol 1e-4"
-    assert d.max() <= 1e-2 * ref.abs().max(), f"{name}: max abs err {float(d.max()):.3e} vs range {float(ref.abs().max()):.3e}"
+    m = dict(inside_frac=inside, max_abs_err=d.max().item(), ref_absmax=ref.abs().max().item(),
+             max_err_over_range=(d.max() / ref.abs().max()).item(),
+             rel_rms_vs_oracle=(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item(),
+             gate_frac=frac, gate_max_rel=max_rel)
     if truth is not None:
         truth = truth.float().cpu()
         e_hip = (got - truth).pow(2).mean().sqrt().item()
         e_ora = (ref - truth).pow(2).mean().sqrt().item()
-        assert e_hip <= 1.3 * e_ora + 1e-6, f"{name}: rms error vs truth {e_hip:.3e} (oracle's own {e_ora:.3e})"
+        m.update(rms_vs_truth_hip=e_hip, rms_vs_truth_oracle=e_ora, truth_ratio=e_hip / max(e_ora, 1e-30), gate_truth_ratio=truth_ratio)
+    record_margin(name or "unnamed", **m)
+    assert inside >= frac, f"{name}: only {inside:.3f} of elements inside rtol 1e-3 / atol 1e-4"
+    assert d.max() <= max_rel * ref.abs().max(), f"{name}: max abs err {float(d.max()):.3e} vs range {float(ref.abs().max()):.3e}"
+    if truth is not None:
+        assert e_hip <= truth_ratio * e_ora + 1e-6, f"{name}: rms error vs truth {e_hip:.3e} (oracle's own {e_ora:.3e})"
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -452,6 +461,73 @@ def test_attention_modules_reference_signatures():
         assert d.abs().max() <= 2e-2 * ref.float().abs().max(), cls.__name__
 
 
+def test_flash_attention_operator_seam():
+    """`univid_amd.wan.attention.flash_attention` = the reference's operator (attention.py:24-130): [B, L, N, C] in any float
+    dtype, per-sample k_lens, result in q's dtype. Against oracle.attention_core (bf16 operands, fp32 softmax) and the fp64
+    softmax; fp32 callers get fp32 back (values on the bf16 grid), fp16 callers stay fp16."""
+    from oracle import wan_dit
+    from univid_amd.wan.attention import attention, flash_attention
+    B, Lq, Lk, N, D = 3, 150, 136, 2, 128
+    g = torch.Generator().manual_seed(77)
+    q, k, v = (torch.randn(B, n, N, D, generator=g) for n in (Lq, Lk, Lk))
+    v[:, :, :, :] += 0.25
+
+    def truth_of(q, k, v, kl):
+        o = torch.zeros(B, Lq, N, D, dtype=torch.float64)
+        for b in range(B):
+            qf, kf, vf = (t[b].double().transpose(0, 1) for t in (q, k[:, :kl[b]], v[:, :kl[b]]))
+            o[b] = (torch.softmax(qf @ kf.transpose(1, 2) / math.sqrt(D), -1) @ vf).transpose(0, 1)
+        return o
+
+    def check(got, ref, truth, name):
+        e_hip, e_ora = (got.double().cpu() - truth).abs(), (ref.double() - truth).abs()
+        tol = 3 * bf16_ulp(truth.float()) + 2e-3 * truth.abs().float().max()
+        record_margin("flash_attention seam: " + name, max_err=e_hip.max(), rms_hip=e_hip.pow(2).mean().sqrt(), rms_oracle=e_ora.pow(2).mean().sqrt())
+        assert (e_hip <= tol).all(), f"{name}: max err {float(e_hip.max()):.3e}"
+        assert e_hip.pow(2).mean().sqrt() <= 1.5 * e_ora.pow(2).mean().sqrt() + 1e-5, name
+
+    qb, kb, vb = q.to(BF16), k.to(BF16), v.to(BF16)
+    # (1) fp32 tensors, ragged k_lens (the self-attention call, model.py:145-150): cast to bf16 inside, fp32 returned
+    klens = torch.tensor([136, 77, 5])
+    out = flash_attention(q.to(DEV), k.to(DEV), v.to(DEV), k_lens=klens, window_size=(-1, -1))
+    assert out.dtype == torch.float32 and tuple(out.shape) == (B, Lq, N, D)
+    assert torch.equal(out, out.to(BF16).float()), "an fp32 caller gets the bf16 result widened, not recomputed"
+    ref = wan_dit.attention_core(q, k, v, k_lens=klens)
+    check(out, ref, truth_of(qb, kb, vb, klens.tolist()), "fp32 in, ragged k_lens")
+    # the same through attention(): the reference's dispatcher (attention.py:133-179)
+    assert torch.equal(attention(q.to(DEV), k.to(DEV), v.to(DEV), k_lens=klens), out)
+    # (2) bf16 tensors, no lens (the cross-attention call, model.py:175): one stacked launch; q_lens = Lq is accepted
+    out2 = flash_attention(qb.to(DEV), kb.to(DEV), vb.to(DEV), q_lens=torch.tensor([Lq] * B))
+    assert out2.dtype == BF16
+    check(out2, wan_dit.attention_core(qb, kb, vb), truth_of(qb, kb, vb, [Lk] * B), "bf16 in, all keys")
+    for b in range(B):   # stacked launch == per-sample launches, bit for bit
+        one = flash_attention(qb[b:b + 1].to(DEV), kb[b:b + 1].to(DEV), vb[b:b + 1].to(DEV))
+        assert torch.equal(one[0], out2[b])
+    # (3) fp16 tensors stay fp16 (half dtypes are never re-cast, attention.py:59-60); softmax_scale is honoured
+    qh, kh, vh = q.half(), k.half(), v.half()
+    out3 = flash_attention(qh.to(DEV), kh.to(DEV), vh.to(DEV), softmax_scale=0.05, dtype=torch.float16)
+    assert out3.dtype == torch.float16
+    t3 = torch.zeros(B, Lq, N, D, dtype=torch.float64)
+    for b in range(B):
+        qf, kf, vf = (t[b].double().transpose(0, 1) for t in (qh, kh, vh))
+        t3[b] = (torch.softmax(qf @ kf.transpose(1, 2) * 0.05, -1) @ vf).transpose(0, 1)
+    assert (out3.double().cpu() - t3).abs().max() <= 4e-3 * t3.abs().max()
+    # (4) head_dim 64, odd Lk (not a multiple of 8: per-sample launches), non-contiguous q
+    q4 = torch.randn(2, 70, 4, 64, generator=g).to(BF16)
+    k4, v4 = (torch.randn(2, 33, 4, 64, generator=g).to(BF16) for _ in range(2))
+    qnc = q4.to(DEV).transpose(1, 2).contiguous().transpose(1, 2)
+    assert not qnc.is_contiguous()
+    out4 = flash_attention(qnc, k4.to(DEV), v4.to(DEV))
+    ref4 = wan_dit.attention_core(q4, k4, v4)
+    assert (out4.float().cpu() - ref4.float()).abs().max() <= 3e-2 and (out4.cpu() == ref4).float().mean() > 0.9
+    # (5) loud errors for what is not built
+    for kw in (dict(causal=True), dict(window_size=(4, 4)), dict(dropout_p=0.1), dict(q_scale=2.0), dict(q_lens=torch.tensor([10, Lq, Lq]))):
+        with pytest.raises((NotImplementedError, ValueError)):
+            flash_attention(qb.to(DEV), kb.to(DEV), vb.to(DEV), **kw)
+    with pytest.raises(L().UnividHipError):
+        flash_attention(qb, kb, vb)                                   # host tensors: no CPU path
+
+
 def test_flash_attention_stacked_samples_match_single_calls():
     """batch > 1: q/k/out rows and V^T COLUMNS are stacked per sample (what one UV_EPI_BF16_T GEMM over the stacked rows
     writes); every sample's result is bit-identical to its own batch-1 call, ragged last key tile included."""
@@ -681,8 +757,8 @@ def test_vae_list_api_and_state_is_reset_between_calls():
     from univid_amd.wan.vae2_2 import Wan2_2_VAE
     g = load_golden("vae_small")
     vae = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=g["seed"])
-    with pytest.raises(TypeError):
-        vae.decode(g["dec_in_0"])
+    # non-list input: logged, answered with None (the reference's `except TypeError`, vae2_2.py:1024-1051)
+    assert vae.decode(g["dec_in_0"]) is None and vae.encode(g["enc_in_0"]) is None
     with torch.no_grad():
         a = vae.decode([g["dec_in_0"].to(DEV), g["dec_in_1"].to(DEV)])
         b = vae.decode([g["dec_in_1"].to(DEV)])

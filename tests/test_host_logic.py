@@ -236,3 +236,52 @@ def test_tokenizer_wrapper_cleaning_and_padding(tmp_path):
     assert ids[0].tolist() == [3, 4, 5, 3, 6, 5] and mask[0].tolist() == [1] * 6          # truncated to seq_len
     assert ids[1].tolist() == [4, 7, 2, 0, 0, 0] and mask[1].tolist() == [1, 1, 1, 0, 0, 0]  # cleaned, unknown word, padded
     assert t("a cat").shape == (1, 6) and t.vocab_size == len(vocab)
+
+
+def test_lora_wrapped_linear_is_rejected_not_ignored():
+    """PEFT's lora.Linear exposes `.weight` = base_layer.weight (reference LoRAManager, model_pipeline.py:340-380): reading it
+    would drop the adapter silently; the weight preparation must refuse it and say how to merge."""
+    from univid_amd.wan.model import _Prepared
+
+    class FakeLoraLinear(torch.nn.Module):      # the attribute surface of peft.tuners.lora.Linear
+        def __init__(self, base):
+            super().__init__()
+            self.base_layer = base
+            self.lora_A = torch.nn.ModuleDict({"default": torch.nn.Linear(base.in_features, 4, bias=False)})
+            self.lora_B = torch.nn.ModuleDict({"default": torch.nn.Linear(4, base.out_features, bias=False)})
+
+        @property
+        def weight(self):
+            return self.base_layer.weight
+
+        @property
+        def bias(self):
+            return self.base_layer.bias
+
+    with pytest.raises(NotImplementedError, match="merge_and_unload"):
+        _Prepared(FakeLoraLinear(torch.nn.Linear(8, 8)))
+    m = WanModel(model_type="ti2v", in_dim=48, out_dim=48, dim=256, ffn_dim=512, num_heads=4, num_layers=1, text_len=32, text_dim=64)
+    m.blocks[0].self_attn.q = FakeLoraLinear(m.blocks[0].self_attn.q)
+    with pytest.raises(NotImplementedError, match="LoRA"):
+        m.blocks[0].self_attn.prepare()
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """A .so built from other kernel sources than the tree's (old local objects after a pull) must not load silently."""
+    from univid_amd import build
+    lib = _lib.load()
+    assert lib.uv_build_id().decode() == build.source_id()
+    monkeypatch.setattr(build, "source_id", lambda: "0" * 24)
+    with pytest.raises(_lib.UnividHipError, match="rebuild"):
+        _lib._check_build_id(lib, _lib.LIB_PATH)
+
+
+def test_calls_refuse_host_or_mixed_device_pointers():
+    """Every entry point runs on the device of its tensors; a host tensor (or tensors of two GPUs) is an error, not a launch."""
+    a = torch.zeros(4, 8)
+    with pytest.raises(_lib.UnividHipError, match="ONE GPU"):
+        _lib.call("uv_cast_f32_bf16", _lib.ptr(a), _lib.ptr(a), 32, _lib.stream_ptr())
+    p, q = _lib.ptr(a), _lib.ptr(a)
+    p.dev, q.dev = 0, 1
+    with pytest.raises(_lib.UnividHipError, match="ONE GPU"):
+        _lib.call("uv_cast_f32_bf16", p, q, 32, _lib.stream_ptr())

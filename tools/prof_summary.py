@@ -16,9 +16,13 @@ def short(name):
     return name if len(name) <= 110 else name[:107] + "..."
 
 
-def stats(path):
+def stats(path, whole=False):
     rows = list(csv.DictReader(open(path)))
-    t0 = min(int(r["Start_Timestamp"]) for r in rows if "flash_attn" in r["Kernel_Name"])
+    if whole:    # VAE runs: no warm-up region to cut; drop torch's own fill / copy / RNG kernels (input generation)
+        rows = [r for r in rows if "at::native" not in r["Kernel_Name"] and "rocclr" not in r["Kernel_Name"] and "rocprim" not in r["Kernel_Name"]]
+        t0 = min(int(r["Start_Timestamp"]) for r in rows)
+    else:
+        t0 = min(int(r["Start_Timestamp"]) for r in rows if "flash_attn" in r["Kernel_Name"])
     rows = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
     agg = collections.defaultdict(list)
     for r in rows:
@@ -63,5 +67,7 @@ def pmc(fetch_path, write_path):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "stats_all":
+        stats(sys.argv[2], whole=True)
     else:
         pmc(sys.argv[2], sys.argv[3])

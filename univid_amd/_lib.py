@@ -20,12 +20,16 @@ SIGNATURES = {
     "uv_version": [],
     "uv_init": [],
     "uv_last_error": [],
+    "uv_build_id": [],
     "uv_device_arch": [_c.c_char_p, _I],
     "uv_gemm_bf16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
     "uv_gemm_f16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
     "uv_gemm_f32_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _P],
     "uv_flash_attn_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "uv_flash_attn_f16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
+    "uv_transpose_16": [_P, _L, _P, _L, _I, _I, _I, _P],
+    "uv_cast_f32_to16": [_P, _P, _L, _I, _P],
+    "uv_cast_16_to_f32": [_P, _P, _L, _I, _P],
     "uv_layernorm_mod": [_P, _L, _P, _L, _I, _I, _F, _I, _P, _L, _I, _I, _P, _P, _P, _I, _I, _P],
     "uv_t5_attention_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _I, _P],
     "uv_add_bf16": [_P, _P, _P, _L, _P],
@@ -58,12 +62,12 @@ SIGNATURES = {
     "uv_vae_video_in": [_P, _P, _L, _I, _I, _I, _I, _I, _P],
     "uv_vae_video_out": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {"uv_last_error": _c.c_char_p}
+_RESTYPE = {"uv_last_error": _c.c_char_p, "uv_build_id": _c.c_char_p}
 
 EPI_BF16, EPI_GELU_BF16, EPI_F32_FROM_BF16, EPI_RESID_F32, EPI_GATE_RESID_F32, EPI_BF16_T = range(6)
 
 _lib = None
-_inited = False
+_inited = set()        # device indices whose arch check + per-device library state (zero page) are done
 
 
 class UnividHipError(RuntimeError):
@@ -85,37 +89,71 @@ def load(path=None):
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, _I)
+    _check_build_id(lib, path)
     _lib = lib
     return lib
 
 
-def init():
-    global _inited
+def _check_build_id(lib, path):
+    """A stale .so next to newer kernel sources (git pull onto old local objects) would run old kernels behind new ctypes
+    signatures: compare the digest compiled into the library with the one of the sources in the tree."""
+    if os.path.abspath(path) != LIB_PATH or not os.path.isdir(os.path.join(_HERE, "csrc")):
+        return
+    from . import build as _build
+    have, want = lib.uv_build_id().decode(), _build.source_id()
+    if have != want:
+        raise UnividHipError(
+            f"{path} was built from other kernel sources (library {have}, tree {want}): rebuild with "
+            "`python -m univid_amd.build`. univid_amd never runs a stale extension.")
+
+
+def init(device=None):
+    """One-time checks for `device` (index; default = the current one): a HIP device is visible, it is a gfx950, and the
+    library's per-device state exists. Called by every entry point with the device of its tensors."""
     lib = load()
-    if not _inited:
+    if device is None:
+        if not torch.cuda.is_available():
+            raise UnividHipError("no HIP device visible: univid_amd's hot path only runs on an MI355X (gfx950)")
+        device = torch.cuda.current_device()
+    if device not in _inited:
         if not torch.cuda.is_available():
             raise UnividHipError("no HIP device visible: univid_amd's hot path only runs on an MI355X (gfx950)")
         torch.cuda.init()
-        rc = lib.uv_init()
-        if rc != 0:
-            raise UnividHipError(f"uv_init failed: {lib.uv_last_error().decode()}")
-        buf = ctypes.create_string_buffer(64)
-        lib.uv_device_arch(buf, 64)
+        with torch.cuda.device(device):
+            rc = lib.uv_init()
+            if rc != 0:
+                raise UnividHipError(f"uv_init failed: {lib.uv_last_error().decode()}")
+            buf = ctypes.create_string_buffer(64)
+            lib.uv_device_arch(buf, 64)
         arch = buf.value.decode()
         if not arch.startswith("gfx950"):
-            raise UnividHipError(f"device arch {arch!r} is not gfx950: the kernels are built for MI355X only")
-        _inited = True
+            raise UnividHipError(f"device {device}: arch {arch!r} is not gfx950: the kernels are built for MI355X only")
+        _inited.add(device)
     return lib
 
 
+class _DevPtr(_c.c_void_p):
+    """A device pointer that remembers which GPU it lives on, so `call` can make that GPU current for the launch."""
+    dev = None
+
+
+class _Stream:
+    """Placeholder for 'the current HIP stream of the device the tensors of this call live on'; resolved in `call`."""
+
+
+_STREAM = _Stream()
+
+
 def stream_ptr():
-    return _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _STREAM
 
 
 def ptr(t):
     if t is None:
         return None
-    return _c.c_void_p(t.data_ptr())
+    p = _DevPtr(t.data_ptr())
+    p.dev = t.device.index if t.device.type == "cuda" else -1
+    return p
 
 
 # Optional live kernel timing (bench.py): PROFILE = {entry_point: []} times those entry points with HIP events
@@ -125,17 +163,34 @@ PROFILE_ALL = False
 
 
 def call(name, *args, flops=0):
-    lib = init()
+    """Launches one entry point on the device its pointer arguments live on (all on ONE device, else an error) and on that
+    device's current stream: `WanTI2V(device_id=1)` / the reference's manual model placement work without the process ever
+    calling torch.cuda.set_device."""
+    dev = None
+    for a in args:
+        if type(a) is _DevPtr:
+            if a.dev != dev:
+                if dev is not None or a.dev < 0:
+                    raise UnividHipError(f"{name}: tensors must live on ONE GPU (got devices {dev} and {a.dev}; -1 = host memory)")
+                dev = a.dev
+    if dev is None:
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    lib = init(dev)
+    if dev != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            return call(name, *args, flops=flops)
+    stream = torch.cuda.current_stream(dev)
+    args = tuple(_c.c_void_p(stream.cuda_stream) if a is _STREAM else a for a in args)
     prof = PROFILE
     timed = prof is not None and (PROFILE_ALL or name in prof)
     if timed:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
+        s.record(stream)
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise UnividHipError(f"{name} failed ({rc}): {lib.uv_last_error().decode()}")
     if timed:
-        e.record()
+        e.record(stream)
         prof.setdefault(name, []).append((s, e, flops))
 
 

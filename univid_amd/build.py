@@ -31,22 +31,55 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _digest(path):
+_TOOL = None
+
+
+def _toolchain_id():
+    """hipcc's version banner: an object built by another compiler is stale even if the source did not change."""
+    global _TOOL
+    if _TOOL is None:
+        try:
+            _TOOL = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            _TOOL = "unknown"
+    return _TOOL
+
+
+def _digest(path, extra=""):
     h = hashlib.sha256()
     for p in [path, os.path.join(CSRC, "common.h")]:
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(_toolchain_id().encode())
+    h.update(extra.encode())
     return h.hexdigest()
+
+
+def source_id():
+    """Digest of every kernel source + common.h + flags (NOT the toolchain: the GPU box may not have the same hipcc banner and
+    only checks that the .so it received belongs to the sources it received). Compiled into the library as uv_build_id();
+    univid_amd._lib.load() compares the two, so a stale .so next to newer sources fails loudly instead of running old kernels
+    behind new ctypes signatures."""
+    h = hashlib.sha256()
+    for p in sources() + [os.path.join(CSRC, "common.h")]:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:24]
 
 
 def _compile(src):
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
-    stamp = obj + ".sha"
-    dig = _digest(src)
+    stamp = obj + ".sha"        # lives next to the object it describes; both are git-ignored
+    extra = []
+    if os.path.basename(src) == "capi.hip":
+        extra = [f'-DUV_BUILD_ID="{source_id()}"']
+    dig = _digest(src, " ".join(extra))
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
@@ -64,11 +97,15 @@ def build(force=False, verbose=True):
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
     newest = max(os.path.getmtime(o) for o in objs)
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+    linked = LIB + ".objs"      # digest list of the objects the library was linked from
+    want = "\n".join(open(o + ".sha").read() for o in objs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest or not os.path.exists(linked) or open(linked).read() != want:
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        with open(linked, "w") as f:
+            f.write(want)
     # a kernel whose host stub was silently dropped shows up as an undefined symbol only at dlopen time
     r = subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({LIB!r})"], capture_output=True, text=True)
     if r.returncode != 0:

@@ -16,7 +16,14 @@ void uv_set_error(const char* fmt, ...) {
 
 extern "C" const char* uv_last_error(void) { return g_err; }
 
-extern "C" int uv_version(void) { return 100; }  // 0.1.0
+extern "C" int uv_version(void) { return 200; }  // 0.2.0
+
+// Digest of the kernel sources this library was built from (univid_amd/build.py: source_id()); the loader compares it with
+// the tree so that a stale .so never runs behind newer bindings.
+#ifndef UV_BUILD_ID
+#define UV_BUILD_ID "unstamped"
+#endif
+extern "C" const char* uv_build_id(void) { return UV_BUILD_ID; }
 
 const float* uv_zero_page();
 

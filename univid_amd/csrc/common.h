@@ -15,6 +15,16 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define UV_WAVE 64
 
+// Host-side per-device state (function attributes, CU count, zero page) is indexed by the CURRENT HIP device: the Python layer
+// makes the tensors' device current around every entry point, so one process can drive several GPUs (reference: manual model
+// placement, models/model_pipeline.py `wan_gpu`).
+#define UV_MAX_DEV 16
+static inline int uv_cur_dev() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return (unsigned)d < UV_MAX_DEV ? d : 0;
+}
+
 // f32 -> bf16, round-to-nearest-even (same rounding torch's .to(bfloat16) uses).
 // A plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN.
 __device__ __forceinline__ bf16_t f2bf(float x) {

@@ -233,7 +233,8 @@ static void launch_conv(ConvArgs& a, hipStream_t stream) {
     a.tiles_n = (a.Cout + BN - 1) / BN;
     auto kern = conv3d_f32_kernel<BM, BN, WM, WN, PREC>;
     const size_t lds = 2 * (BM + BN) * 128;
-    static bool attr = false;
+    static bool attr_set[UV_MAX_DEV];
+    bool& attr = attr_set[uv_cur_dev()];
     if (!attr) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;

@@ -666,11 +666,12 @@ static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
 #define UV_LAUNCH8(E)                                                                              \
     case E: {                                                                                      \
         auto kern = gemm_bf16_8ph_kernel<E, VAR, F16>;                                               \
-        static bool attr_set = false;                                                              \
-        if (!attr_set) {                                                                           \
+        static bool attr_set[UV_MAX_DEV];                                                          \
+        bool& attr_done = attr_set[uv_cur_dev()];                                                  \
+        if (!attr_done) {                                                                          \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                 (int)lds);                                                         \
-            attr_set = true;                                                                       \
+            attr_done = true;                                                                      \
         }                                                                                          \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                     \
         break;                                                                                     \
@@ -701,11 +702,12 @@ static int launch_cfg(const GemmArgs& a0, int epi, hipStream_t stream) {
 #define UV_LAUNCH(E)                                                                               \
     case E: {                                                                                      \
         auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, E, NS, F16>;                                \
-        static bool attr_set = false;                                                              \
-        if (!attr_set) {                                                                           \
+        static bool attr_set[UV_MAX_DEV];                                                          \
+        bool& attr_done = attr_set[uv_cur_dev()];                                                  \
+        if (!attr_done) {                                                                          \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                 (int)lds);                                                         \
-            attr_set = true;                                                                       \
+            attr_done = true;                                                                      \
         }                                                                                          \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                     \
         break;                                                                                     \
@@ -727,11 +729,11 @@ static int launch_cfg(const GemmArgs& a0, int epi, hipStream_t stream) {
 }
 
 static int num_cus() {
-    static int n = 0;
+    static int cus[UV_MAX_DEV];
+    const int dev = uv_cur_dev();
+    int& n = cus[dev];
     if (!n) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     }
     return n;
 }

@@ -134,13 +134,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_nt_kernel(GemmF32Args p)
     }
 }
 
-static float* g_zero_page = nullptr;
-const float* uv_zero_page() {
-    if (!g_zero_page) {
-        if (hipMalloc(&g_zero_page, 4096) != hipSuccess) return nullptr;
-        hipMemset(g_zero_page, 0, 4096);
+static float* g_zero_page[UV_MAX_DEV];
+const float* uv_zero_page() {   // one per device; allocated by uv_init() (outside any stream capture)
+    float*& z = g_zero_page[uv_cur_dev()];
+    if (!z) {
+        if (hipMalloc(&z, 4096) != hipSuccess) return nullptr;
+        hipMemset(z, 0, 4096);
     }
-    return g_zero_page;
+    return z;
 }
 
 extern "C" int uv_gemm_f32_nt(const float* A, long lda, const float* W, long ldw, const float* bias, int M, int N,
@@ -160,7 +161,8 @@ extern "C" int uv_gemm_f32_nt(const float* A, long lda, const float* W, long ldw
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     auto kern = gemm_f32_nt_kernel<BM, BN, 2, 2>;
     const size_t lds = 2 * (BM + BN) * 128;
-    static bool attr = false;
+    static bool attr_set[UV_MAX_DEV];
+    bool& attr = attr_set[uv_cur_dev()];
     if (!attr) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, (hipStream_t)stream, a);
     UV_CHECK_LAUNCH("uv_gemm_f32_nt");

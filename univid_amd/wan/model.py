@@ -49,6 +49,14 @@ class _Prepared:
     __slots__ = ("w", "b")
 
     def __init__(self, lin: nn.Linear, pad_k: int = 0):
+        if hasattr(lin, "base_layer") or hasattr(lin, "lora_A"):
+            # PEFT's lora.Linear (what the reference's LoRAManager installs on q/k/v/o/ffn.0/ffn.2, model_pipeline.py:340-380)
+            # exposes `.weight` = base_layer.weight: reading it would silently DROP the adapter. The fused kernels consume one
+            # dense weight per projection, so the deltas have to be folded in first.
+            raise NotImplementedError(
+                "a LoRA-wrapped nn.Linear (PEFT lora.Linear) was found in the DiT: the HIP path reads dense weights and would "
+                "ignore the adapter. Fold the adapters in with `peft_model.merge_and_unload()` (or LoRAManager's merge), then "
+                "call `WanModel.invalidate()` before the next forward.")
         w = lin.weight.detach()
         if pad_k and w.shape[1] % pad_k:
             w = torch.nn.functional.pad(w, (0, pad_k - w.shape[1] % pad_k))
@@ -330,13 +338,24 @@ def _zeros_cached(key, shape, dtype, device):
     return t
 
 
+_vt_user = {}
+
+
 def _vt_scratch(tag, C, batch, L, device):
-    """V^T [C, columns]: sample b's keys are columns [b*L, (b+1)*L); the tail up to the 64-key tile bound stays zero."""
+    """V^T [C, columns]: sample b's keys are columns [b*L, (b+1)*L); the tail [batch*L, columns) up to the 64-key tile bound is
+    zero. The attention kernels mask the scores of those columns to -inf (P = 0 exactly), so the contract they need is only
+    that the tail is FINITE (0 * NaN would poison the row); it is kept zero here: different (batch, L) pairs can give the same
+    column count, and then the previous user's V values would sit in the new user's tail - it is re-zeroed on such a change."""
     if batch > 1 and L % 8:
         raise NotImplementedError(f"stacked samples need a token count divisible by 8 (got {L}); run them one by one")
     cols = (batch - 1) * L + _round_up(L, 64)
     # one scratch per stream: forwards running concurrently on different streams must not share it
-    return _zeros_cached((tag, device, torch.cuda.current_stream(device).cuda_stream), (C, cols), BF16, device)
+    key = (tag, device, torch.cuda.current_stream(device).cuda_stream)
+    t = _zeros_cached(key, (C, cols), BF16, device)
+    if _vt_user.get(key, (batch, L, t.data_ptr())) != (batch, L, t.data_ptr()) and cols > batch * L:
+        t[:, batch * L:].zero_()
+    _vt_user[key] = (batch, L, t.data_ptr())
+    return t
 
 
 def _ensure_prepared(mod):

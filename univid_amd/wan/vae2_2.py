@@ -487,11 +487,16 @@ class Wan2_2_VAE:
         self.model.precision = precision
 
     def encode(self, videos):
+        """List in, list out; a non-list argument is logged and answered with None, as the reference does (vae2_2.py:1024-1036:
+        its `except TypeError` turns the check into a logged None)."""
         if not isinstance(videos, list):
-            raise TypeError("videos should be a list")
+            logging.warning("Wan2_2_VAE.encode: videos should be a list")
+            return None
         return [self.model.encode(u.to(self.device).unsqueeze(0), self.scale).float().squeeze(0) for u in videos]
 
     def decode(self, zs):
+        """vae2_2.py:1038-1051; non-list -> logged None (see encode)."""
         if not isinstance(zs, list):
-            raise TypeError("zs should be a list")
+            logging.warning("Wan2_2_VAE.decode: zs should be a list")
+            return None
         return [self.model.decode(u.to(self.device).unsqueeze(0), self.scale).float().squeeze(0) for u in zs]
