@@ -128,8 +128,10 @@ def gen_unipc(ns):
     save("unipc", x=x, model_outputs=outs, trajectory=torch.stack(traj), **arrs)
 
 
-def gen_sampler(ns):
-    print("sampler_tiny")
+def gen_sampler(ns, steps=10, keep=(0, 1, 2, 5, 9), name="sampler_tiny"):
+    """t2v + i2v trajectories of the tiny DiT through the reference pieces. `sampler_tiny`: 10 steps; `sampler_tiny_50`: the
+    50 flow steps BASELINE config 2 names (textimage2video.py:367-394 with sampling_steps=50), 6 of them kept."""
+    print(name)
     cfg = wan_dit.TINY_CFG
     m = ref_dit(ns, cfg, 0)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -138,7 +140,8 @@ def gen_sampler(ns):
     ctx = torch.randn(20, cfg["text_dim"], generator=g)
     ctxn = torch.randn(7, cfg["text_dim"], generator=g)
     z = torch.randn(48, 1, 16, 16, generator=g)
-    steps, shift, gs = 10, 5.0, 5.0
+    shift, gs = 5.0, 5.0
+    keep = list(keep)
     S = ns.unipc.FlowUniPCMultistepScheduler
     arrs = {}
     for mode in ("t2v", "i2v"):
@@ -170,11 +173,11 @@ def gen_sampler(ns):
             mine = sampler.denoise(sd, cfg, noise, [ctx], [ctxn], steps, shift, gs, z=(z if i2v else None), record=rec)
         for (a, b), (c_, d) in zip(rec_ref, rec):
             assert torch.equal(a, c_) and torch.equal(b, d), "oracle sampler != reference"
-        keep = [0, 1, 2, 5, 9]                                      # per-step tensors kept (all were checked above)
+        # per-step tensors kept (ALL steps were checked bit-identical above)
         arrs[f"{mode}_noise_pred"] = torch.stack([rec_ref[i][0] for i in keep])
         arrs[f"{mode}_latents"] = torch.stack([rec_ref[i][1] for i in keep])
         arrs["kept_steps"] = torch.tensor(keep)
-    save("sampler_tiny", seed=0, steps=steps, shift=shift, guide_scale=gs, noise=noise, ctx=ctx, ctx_null=ctxn, z=z, **arrs)
+    save(name, seed=0, steps=steps, shift=shift, guide_scale=gs, noise=noise, ctx=ctx, ctx_null=ctxn, z=z, **arrs)
 
 
 def gen_vae(ns):
@@ -345,7 +348,8 @@ def main():
     torch.set_num_threads(8)
     only = sys.argv[1:]
     gens = {"unipc": lambda: gen_unipc(ns), "masks": gen_masks, "text_weight": gen_text_weight, "dit_tiny": lambda: gen_dit_tiny(ns),
-            "sampler": lambda: gen_sampler(ns), "vae": lambda: gen_vae(ns), "block": lambda: gen_dit_block_3072(ns),
+            "sampler": lambda: gen_sampler(ns),
+            "sampler50": lambda: gen_sampler(ns, steps=50, keep=(0, 1, 10, 25, 40, 49), name="sampler_tiny_50"), "vae": lambda: gen_vae(ns), "block": lambda: gen_dit_block_3072(ns),
             "siglip2": gen_siglip2, "projector": gen_projector, "t5": gen_t5}
     for k, fn in gens.items():
         if not only or k in only:

@@ -47,7 +47,7 @@ def rope_table(head_dim):
 def rope_apply(x, grid_sizes, freqs):
     """model.py:38-66 - x [B, L, N, D]; rotation in complex128, fp32 result; rows past f*h*w pass through."""
     n, c = x.size(2), x.size(3) // 2
-    fa, fb, fc = freqs.split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
+    fa, fb, fc = freqs.to(x.device).split([c - 2 * (c // 3), c // 3, c // 3], dim=1)   # (device move: a no-op on the CPU)
     out = []
     for i, (f, h, w) in enumerate(grid_sizes.tolist()):
         s = f * h * w

@@ -81,8 +81,11 @@ def test_dit_block_ti2v5b_width():
         assert torch.equal(out, g["out_" + name])
 
 
-def test_sampler_trajectories():
-    g = load_golden("sampler_tiny")
+@pytest.mark.parametrize("fixture", ["sampler_tiny", "sampler_tiny_50"])
+def test_sampler_trajectories(fixture):
+    """10-step and 50-step (BASELINE config 2's step count) t2v / i2v trajectories: the oracle loop reproduces the reference
+    pieces' latents bit for bit at every kept step."""
+    g = load_golden(fixture)
     cfg = wan_dit.TINY_CFG
     sd = wan_dit.make_state_dict(cfg, g["seed"])
     keep = g["kept_steps"].tolist()
