@@ -9,10 +9,12 @@ update, on a 49-frame 704x1280 latent [48,13,44,80] (L = 11 440 tokens; SURVEY.m
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 is launched by the driver through torch.distributed.run (one process per GPU, RCCL): every rank denoises
-its OWN sample (independent diffusion samples shard one per GPU, no data-path collective) and the final latents
-are all-gathered once over xGMI at the end of the timed region; value = N*K / max-over-ranks time ("weak").
-Rank 0 prints ONE JSON line.
+N > 1: one process per GPU over RCCL (torch.distributed backend "nccl"): every rank denoises its OWN sample (independent
+diffusion samples shard one per GPU, no data-path collective) and the final latents are all-gathered once over xGMI at
+the end of the timed region; value = N*K / max-over-ranks time ("weak"). Rank 0 prints ONE JSON line.
+The driver starts the ranks through `python -m torch.distributed.run ... bench.py --gpus N`; a BARE `python bench.py --gpus N`
+works too: the parent, before it touches the GPU in any way, starts that same launcher as a CHILD process and relays its
+output (never an exec of a process that initialised HIP).
 """
 import argparse
 import json
@@ -53,27 +55,82 @@ def build_model(cfg, device, seed=0):
     return m
 
 
-def vae_decode_metric(device, precision):
-    """BASELINE.json's second metric: Wan2.2 VAE decode of a 49-frame 720x1280 clip (config 4), random-init weights.
-    precision 'fp32' = exact f32 MFMA like the reference (vae2_2.py:897); 'bf16x3' = split-bf16 3-pass MFMA convolutions
-    (within rtol 1e-3 / atol 1e-4 of the fp32 reference, tests/test_gpu_parity.py). GB/s = fp32 RGB bytes out / decode
-    time; tflops = 835.4 TFLOP per decode / time; f32 MFMA peak 157.3 TFLOP/s."""
+VAE_DECODE_TFLOP, VAE_ENCODE_TFLOP = 835.4, 159.1      # 49x720x1280, SURVEY 8(d) (FlopCounter on meta tensors)
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def _vae_bound(precision, tflops):
+    """fp32 = exact f32 MFMA: bound is the f32 matrix peak. bf16x3 executes 3 bf16 MFMA passes per product, so its bound in
+    ALGORITHMIC flops is the bf16 peak / 3 (an f32-peak fraction would read > 1 and means nothing)."""
+    if precision == "fp32":
+        return {"bound_tflops": PEAK_F32_MFMA_TFLOPS, "vs_bound": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "bound": "f32 MFMA peak"}
+    return {"bound_tflops": round(PEAK_BF16_TFLOPS / 3, 1), "vs_bound": round(tflops / (PEAK_BF16_TFLOPS / 3), 4),
+            "bound": "bf16 MFMA peak / 3 passes"}
+
+
+def vae_metrics(device, precision, encode=True):
+    """BASELINE.json's second metric (config 4): Wan2.2 VAE on a 49-frame 720x1280 clip, random-init weights: encode
+    [3,49,720,1280] -> [48,13,45,80] (vae2_2.py:783-810) and decode back (:812-839). precision 'fp32' = exact f32 MFMA, the
+    reference's dtype (vae2_2.py:897) and the HEADLINE; 'bf16x3' = opt-in split-bf16 3-pass convolutions (drops the lo*lo term:
+    narrower than fp32, inside rtol 1e-3 / atol 1e-4 of it, tests/test_gpu_parity.py) - reported under its own key only.
+    GB/s = fp32 RGB bytes (out for decode, in for encode) / time."""
     from univid_amd.wan.vae2_2 import Wan2_2_VAE
     vae = Wan2_2_VAE(device=device, seed=0, precision=precision)
     g = torch.Generator(device=device).manual_seed(7)
-    z = torch.randn(48, 13, 45, 80, device=device, generator=g)
+    res = {}
     with torch.no_grad():
+        z = torch.randn(48, 13, 45, 80, device=device, generator=g)
         vae.decode([z[:, :2].contiguous()])                      # warm-up (allocations, kernel load)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         v = vae.decode([z])[0]
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    nbytes = v.numel() * 4
-    return {"metric": "vae_decode_GBps", "value": round(nbytes / dt / 1e9, 4), "unit": "GB/s", "seconds": round(dt, 3),
-            "clip": "49x720x1280 RGB from latent [48,13,45,80]", "dtype": "f32" if precision == "fp32" else "bf16x3 (f32 accumulate)",
-            "tflops": round(835.4 / dt, 1), "vs_f32_mfma_peak": round(835.4 / dt / 157.3, 4),
-            "finite": bool(torch.isfinite(v).all().item())}
+        tf = VAE_DECODE_TFLOP / dt
+        res["decode"] = {"metric": "vae_decode_GBps", "value": round(v.numel() * 4 / dt / 1e9, 4), "unit": "GB/s", "seconds": round(dt, 3),
+                         "clip": "49x720x1280 RGB from latent [48,13,45,80]", "dtype": "f32" if precision == "fp32" else "bf16x3 (f32 accumulate)",
+                         "tflops": round(tf, 1), **_vae_bound(precision, tf), "finite": bool(torch.isfinite(v).all().item())}
+        if encode:
+            video = v.clamp_(-1, 1)                              # a [3,49,720,1280] clip in [-1, 1]: the decode's own output
+            vae.encode([video[:, :5].contiguous()])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            zz = vae.encode([video])[0]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            tf = VAE_ENCODE_TFLOP / dt
+            res["encode"] = {"metric": "vae_encode_GBps", "value": round(video.numel() * 4 / dt / 1e9, 4), "unit": "GB/s", "seconds": round(dt, 3),
+                             "clip": "49x720x1280 RGB -> latent " + str(list(zz.shape)), "dtype": "f32" if precision == "fp32" else "bf16x3 (f32 accumulate)",
+                             "tflops": round(tf, 1), **_vae_bound(precision, tf), "finite": bool(torch.isfinite(zz).all().item())}
+    return res
+
+
+def cpu_baseline_vae(budget_s=12.0):
+    """VAE leg of the CPU baseline: the oracle's fp32 VAE decoder (oracle/wan_vae.py, bit-identical to the reference module) on
+    this host, FULL width, 720x1280, on a BOUNDED number of latent frames (the streaming decoder works one latent frame per
+    chunk: chunk 0 -> 1 frame, every later chunk -> 4 frames), extrapolated to the 13-latent-frame clip by output frames."""
+    from oracle import wan_vae
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = wan_vae.FULL_CFG
+    vae = wan_vae.WanVAE(wan_vae.make_state_dict(cfg, 0), cfg)
+    scale = wan_vae.scale_tensors()
+    g = torch.Generator().manual_seed(7)
+    z = torch.randn(1, 48, 2, 45, 80, generator=g)
+    with torch.no_grad():
+        t0 = time.time()
+        v = vae.decode(z[:, :, :1], scale)
+        t1 = time.time() - t0
+        frames, secs, nlat = v.shape[2], t1, 1
+        if t1 < budget_s / 5:        # fast host: add a steady-state chunk (4 frames per latent frame)
+            t0 = time.time()
+            v = vae.decode(z, scale)
+            secs, frames, nlat = time.time() - t0, v.shape[2], 2
+    per_frame = secs / frames
+    full = per_frame * 49
+    return {"value": round(3 * 49 * 720 * 1280 * 4 / full / 1e9, 6), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/wan_vae.WanVAE.decode (fp32, full width) of {nlat} latent frame(s) [48,{nlat},45,80] -> {frames} frame(s) "
+                      f"720x1280 in {secs:.1f} s on {cores} threads; full 49-frame clip extrapolated by output frames = {full:.0f} s"}
 
 
 def cpu_baseline(cfg, budget_s=25.0):
@@ -142,9 +199,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # bare `python bench.py --gpus N`: this process has NOT touched the GPU (no torch.cuda / HIP call so far); start the
+        # launcher as a child, one rank per GPU, and pass its output (rank 0's JSON line) and exit code through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     if world != args.gpus:
-        if args.gpus != 1 and world == 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: start one rank per GPU "
+                         f"(`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`)")
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -239,7 +308,7 @@ def main():
             avg_ms = sum(s.elapsed_time(e) for s, e, _ in self_ev) / len(self_ev)
             launch_flops = self_ev[0][2]     # 2 samples (cond + uncond) per launch
             achieved = launch_flops / (avg_ms * 1e-3) / 1e12
-            traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.md), not live
+            traffic = None   # HBM-side bytes per launch: PMC counters cannot be read in-process; taken from the committed passes
             try:
                 traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["self_attention_L11440"]["traffic_bytes_per_launch"]
                 traffic *= prof["uv_flash_attn_bf16"][0][2] / self_attn_flops(L_TOKENS, cfg["dim"])   # samples per launch
@@ -247,9 +316,13 @@ def main():
                 pass
             if args.shape != "A":
                 traffic = None    # the PMC passes were taken at shape A
-            roofline = {"kernel": f"flash_attn_fwd12_kernel (self-attention, cond+uncond batch 2 x Lq=Lk={L_TOKENS}, 24 heads)", "bound": "mfma",
+            nsamp = round(launch_flops / self_attn_flops(L_TOKENS, cfg["dim"]))
+            roofline = {"kernel": f"{_lib.attn_kernel_name(L_TOKENS, L_TOKENS, cfg['dim'] // cfg['num_heads'], nsamp)} (self-attention, "
+                                  f"{nsamp} stacked sample(s) x Lq=Lk={L_TOKENS}, {cfg['num_heads']} heads; name = what the dispatcher selected)",
+                        "bound": "mfma",
                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": None if traffic is None else "committed PMC passes (profiles/pmc_traffic.json <- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not this run",
                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(self_ev),
                         "flops_per_launch": launch_flops}
         step_flops = 2 * dit_forward_flops(L_TOKENS, cfg)
@@ -270,11 +343,17 @@ def main():
         }
         if args.kernel_times:
             out["kernel_times"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in ktimes.items()}
+        out["rccl_ranks"] = world if world > 1 else 0
         if world == 1 and not args.no_vae and not args.layers and args.shape == "A":
-            out["vae_decode"] = vae_decode_metric(device, "bf16x3")
-            out["vae_decode_fp32"] = vae_decode_metric(device, "fp32")
+            del model                                            # the 30 GB of DiT weights are not needed any more
+            torch.cuda.empty_cache()
+            f32 = vae_metrics(device, "fp32")                    # the reference's dtype: the headline VAE numbers
+            out["vae_decode"], out["vae_encode"] = f32["decode"], f32["encode"]
+            out["vae_decode_bf16x3"] = vae_metrics(device, "bf16x3", encode=False)["decode"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dict(TI2V_5B_CFG))
+            if not args.no_vae:
+                out["cpu_baseline"]["vae_decode"] = cpu_baseline_vae()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -70,6 +70,10 @@ int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const v
 int uv_flash_attn_f16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                       int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream);
 
+/* Name of the kernel uv_flash_attn_bf16 (f16 = 0) / uv_flash_attn_f16 (f16 = 1) dispatches for a problem of this geometry
+ * (selection depends on Lk, head_dim and the leading dimensions only); for benchmark / profile labels. Host-only. */
+int uv_flash_attn_kernel_name(int Lk, int head_dim, long ldk, long ldvt, int f16, char* buf, int len);
+
 /* Operator-seam helpers: what flash_attention(q, k, v, ...) (attention.py:24-130) does around the core when it is handed
  * [B, L, N, C] tensors of any float dtype: `half(x)` casts (:59-83), and `.type(out_dtype)` of the result (:130); the
  * transpose produces the V^T operand of uv_flash_attn_* from token-major V rows.

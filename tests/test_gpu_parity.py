@@ -75,9 +75,12 @@ def assert_f32_close(got, ref, rtol=1e-3, atol=1e-4, name=""):
     assert bad == 0, f"{name}: {bad}/{ref.numel()} outside rtol={rtol} atol={atol}; max abs {float((got - ref).abs().max()):.3e}"
 
 
-def assert_model_close(got, ref, truth=None, frac=0.90, name="", max_rel=1e-2, truth_ratio=1.3):
-    """Composite-path gate; the measured numbers go to the margins file (conftest.record_margin) so `frac`, `max_rel` and
-    `truth_ratio` can be ratcheted against what the driver box measured (profiles/r02_parity_margins.json)."""
+def assert_model_close(got, ref, truth=None, frac=0.93, name="", max_rel=6e-4, truth_ratio=1.02):
+    """Composite-path gate: fraction of elements inside rtol 1e-3 / atol 1e-4, max |err| / range, and rms error against the
+    no-rounding truth run relative to the oracle's own. Every gate is what MI355X measured (profiles/r02_parity_margins.json)
+    x 1.5 - for a fraction: 1.5 x the measured OUTSIDE fraction. The defaults are the tiny-DiT forwards (measured 95.6-96.1 %
+    inside, max 3.8e-4 of the range, truth ratio 0.999-1.001); wider models pass their own numbers. The measured values are
+    written to the margins file again on every run (conftest.record_margin)."""
     got, ref = got.float().cpu(), ref.float().cpu()
     assert torch.isfinite(got).all(), name
     d = (got - ref).abs()
@@ -576,6 +579,44 @@ def test_dit_batched_forward_is_bit_identical_to_sequential():
     assert torch.equal(mixed[0], a) and torch.equal(mixed[1], s_alone)
 
 
+def test_context_cache_is_bit_identical_and_tracks_changes():
+    """text_embedding and the blocks' cross-attention K / V^T of the context are computed once per context (they depend on
+    neither latent nor timestep, model.py:170-172, 472-478): cached forwards must equal uncached ones bit for bit, an in-place
+    edit of a context tensor or new weights must invalidate, and mixed-shape batches keep one entry per sample group."""
+    g = load_golden("dit_tiny")
+    cfg, sd, m = _tiny_model(g["seed"])
+    Lt = 256
+    x, ctx = g["x"].to(DEV), g["ctx"].to(DEV).clone()
+    ta, tb = g["t_one"].to(DEV), torch.full((1, Lt), 321.0, device=DEV)
+    with torch.no_grad():
+        m.cache_context = False
+        ra, rb = m([x], ta, [ctx], Lt)[0], m([x], tb, [ctx], Lt)[0]
+        m.cache_context = True
+        a = m([x], ta, [ctx], Lt)[0]
+        gen = m._ctx_gen
+        b = m([x], tb, [ctx], Lt)[0]                      # second step: same context tensors -> cache hit
+        assert m._ctx_gen == gen and len(m.blocks[0].cross_attn._kv_cache) == 1
+        assert torch.equal(a, ra) and torch.equal(b, rb)
+        ctx.mul_(0.5)                                     # in-place edit: _version changes -> recomputed
+        c = m([x], ta, [ctx], Lt)[0]
+        assert m._ctx_gen == gen + 1 and not torch.equal(c, ra)
+        m.cache_context = False
+        assert torch.equal(c, m([x], ta, [ctx], Lt)[0])
+        m.cache_context = True
+        # the CFG pair (stacked) and a mixed-shape batch (two groups) under one context generation
+        small = torch.randn(48, 2, 8, 8, device=DEV)
+        pair = m([x, x], torch.cat([ta, ta]), [ctx, ctx * 2], Lt)
+        mixed = m([x, small], torch.cat([ta, ta]), [ctx, ctx * 2], Lt)
+        assert torch.equal(pair[0], c) and torch.equal(mixed[0], c)
+        # new weights: load_state_dict -> invalidate() -> nothing stale
+        sd2 = {k: (v * 1.01 if "cross_attn.k.weight" in k else v) for k, v in sd.items()}
+        m.load_state_dict(sd2)
+        d = m([x], ta, [ctx], Lt)[0]
+        assert not torch.equal(d, c)
+        m.cache_context = False
+        assert torch.equal(d, m([x], ta, [ctx], Lt)[0])
+
+
 def test_dit_head_dim_128_and_odd_grid():
     from oracle import wan_dit
     cfg, sd, m = _tiny_model(3, num_heads=2)
@@ -620,8 +661,8 @@ def test_dit_block_ti2v5b_width_vs_golden():
         wan_dit.BF16 = old
     # at width 3072 the reference's own bf16 roundings put BOTH implementations ~1e-3 (rms) from the truth; the two
     # differ from each other by less than either differs from the truth
-    assert_model_close(out[0], g["out_f32"][0], truth[0], frac=0.70, name="block f32 stream")
-    assert_model_close(outb[0], g["out_bf16"][0], frac=0.70, name="block bf16 stream (block 0)")
+    assert_model_close(out[0], g["out_f32"][0], truth[0], frac=0.62, max_rel=3.2e-3, name="block f32 stream")   # measured 74.5 %, 1.7e-3, 1.003
+    assert_model_close(outb[0], g["out_bf16"][0], frac=0.62, max_rel=3.2e-3, name="block bf16 stream (block 0)")   # measured 74.5 %, 2.1e-3
     # fused path: 2 modulation rows + token->row map instead of a per-token table
     from univid_amd.wan.model import _freqs_device
     x = g["x"][0].to(DEV).clone()
@@ -666,7 +707,12 @@ def test_dit_block_ti2v5b_width_1014_tokens_vs_oracle():
         blk.prepare()
         blk._run(xs, Lt, e_rows.reshape(2, -1).to(DEV), tid.to(torch.int32).to(DEV), grid, _freqs_device(freqs, torch.device(DEV)),
                  ctx[0].to(DEV), first_block=False)
-    assert_model_close(xs, ref[0], truth[0], frac=0.70, name="TI2V-5B block, L=1014")
+    assert_model_close(xs, ref[0], truth[0], frac=0.77, max_rel=2.7e-3, name="TI2V-5B block, L=1014")   # measured 84.7 %, 1.7e-3, 1.0003
+
+
+def SAMPLER10_GATE(what):
+    # 10 steps take 5x larger steps than 50: measured (profiles/r02_parity_margins.json) x 1.5
+    return 5e-3 if what.startswith("noise_pred") else 3e-3
 
 
 def test_sampler_trajectories_vs_golden():
@@ -681,12 +727,15 @@ def test_sampler_trajectories_vs_golden():
             final = pipe.denoise(g["noise"].to(DEV), [g["ctx"].to(DEV)], [g["ctx_null"].to(DEV)], g["steps"], g["shift"],
                                  g["guide_scale"], z=(g["z"].to(DEV) if mode == "i2v" else None), record=rec)
         assert len(rec) == g["steps"] and torch.equal(final, rec[-1][1])
+        meas = {}
         for j, i in enumerate(keep):
             ref_np, ref_lat = g[f"{mode}_noise_pred"][j], g[f"{mode}_latents"][j]
-            # CFG (x5) and 10 sampler steps amplify the bf16 noise of the DiT: gate on relative RMS error
+            # CFG (x5) and the sampler steps amplify the bf16 noise of the DiT: gate on relative RMS error
             for got, ref, what in ((rec[i][0], ref_np, "noise_pred"), (rec[i][1], ref_lat, "latent")):
-                rel = (got.cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()
-                assert rel < (5e-3 if i == 0 else 3e-2), f"{mode} {what} step {i}: rel rms {float(rel):.3e}"
+                meas[f"{what}_step{i}"] = _rel_rms(got, ref)
+        record_margin(f"10-step {mode} trajectory (tiny DiT) rel rms vs reference", **meas)
+        for k, v in meas.items():
+            assert v < SAMPLER10_GATE(k), f"{mode} {k}: rel rms {v:.3e}"
         if mode == "i2v":
             assert torch.equal(final[:, 0].cpu(), g["z"][:, 0]), "i2v must keep the first latent frame pinned to z"
 
@@ -718,15 +767,15 @@ def test_sampler_50_step_trajectories_vs_golden():
             meas[f"latent_step{i}"] = _rel_rms(rec[i][1], g[f"{mode}_latents"][j])
         record_margin(f"50-step {mode} trajectory (tiny DiT) rel rms vs reference", **meas)
         for k, v in meas.items():
-            step = int(k.rsplit("step", 1)[1])
-            assert v < SAMPLER50_GATE(step), f"{mode} {k}: rel rms {v:.3e}"
+            assert v < SAMPLER50_GATE(k), f"{mode} {k}: rel rms {v:.3e}"
         if mode == "i2v":
             assert torch.equal(final[:, 0].cpu(), g["z"][:, 0])
 
 
-def SAMPLER50_GATE(step):
-    # measured on MI355X (profiles/r02_parity_margins.json) x 1.5; step 0 has no sampler history behind it
-    return 5e-3 if step == 0 else 3e-2
+def SAMPLER50_GATE(what):
+    # measured on MI355X (profiles/r02_parity_margins.json): noise_pred 1.9e-3 (step 0) growing to 3.0e-3 (step 49) - CFG's x5
+    # on the DiT's bf16 noise -, latents 2.5e-6 growing to 2.1e-4 over the 50 steps. Gates = 1.5 x the largest measured value.
+    return 4.6e-3 if what.startswith("noise_pred") else 3.2e-4
 
 
 def test_dit_stack_ti2v5b_width_depth_vs_oracle():
@@ -763,13 +812,16 @@ def test_dit_stack_ti2v5b_width_depth_vs_oracle():
     assert len(hidden) == 8
     for depth in (1, 2, 4, 8):
         assert_model_close(hidden[depth - 1], ref_h[depth - 1][0], tru_h[depth - 1][0], frac=DEPTH_GATE[depth][0],
-                           max_rel=DEPTH_GATE[depth][1], truth_ratio=1.15, name=f"TI2V-5B width, residual stream after block {depth} (L=520)")
-    assert_model_close(out, ref[0], tru[0], frac=DEPTH_GATE["out"][0], max_rel=DEPTH_GATE["out"][1], truth_ratio=1.15,
+                           max_rel=DEPTH_GATE[depth][1], truth_ratio=1.02, name=f"TI2V-5B width, residual stream after block {depth} (L=520)")
+    assert_model_close(out, ref[0], tru[0], frac=DEPTH_GATE["out"][0], max_rel=DEPTH_GATE["out"][1], truth_ratio=1.02,
                        name="TI2V-5B width, 8-block forward output (L=520)")
 
 
-# (min fraction inside rtol 1e-3 / atol 1e-4, max |err| / range): measured on MI355X x 1.5 margin, see profiles/r02_parity_margins.json
-DEPTH_GATE = {1: (0.60, 1e-2), 2: (0.50, 1e-2), 4: (0.40, 1e-2), 8: (0.30, 1.5e-2), "out": (0.30, 1.5e-2)}
+# (min fraction inside rtol 1e-3 / atol 1e-4, max |err| / range). Measured on MI355X (profiles/r02_parity_margins.json): inside
+# 94.8 / 87.6 / 75.4 / 60.5 % after 1 / 2 / 4 / 8 blocks and 41 % at the head output, max error 2.4-2.8e-3 of the range, relative
+# rms vs the oracle 5.0e-4 x sqrt(depth) (a random walk of bf16 rounding flips), rms-vs-truth ratio 0.9999-1.0017 at every depth.
+# Gates = 1.5 x the measured outside fraction / max error.
+DEPTH_GATE = {1: (0.92, 3.7e-3), 2: (0.81, 3.7e-3), 4: (0.63, 3.6e-3), 8: (0.41, 4.2e-3), "out": (0.27, 2.2e-3)}
 
 
 def test_config2_shape_two_blocks_vs_eager_oracle():
@@ -806,7 +858,10 @@ def test_config2_shape_two_blocks_vs_eager_oracle():
     assert torch.equal(out, again), "forward must be deterministic"
     assert torch.equal(out, padded), "sequence padding changed the valid tokens"
     assert torch.equal(pair[0], out) and torch.equal(pair[1], unc) and not torch.equal(out, unc)
-    assert_model_close(out, ref, tru, frac=0.50, truth_ratio=1.15, name="config 2 shape [48,13,30,52] L=5070, 2 blocks, vs eager oracle on GPU")
+    # measured (profiles/r02_parity_margins.json): 23 % inside, max 2.9e-3 of the range, HIP rms-vs-truth 0.88x the eager run's own
+    # (torch-ROCm's SDPA / GEMM kernels sit further from the unrounded result than the HIP kernels do)
+    assert_model_close(out, ref, tru, frac=0.15, max_rel=4.5e-3, truth_ratio=1.05,
+                       name="config 2 shape [48,13,30,52] L=5070, 2 blocks, vs eager oracle on GPU")
 
 
 
@@ -835,6 +890,83 @@ def test_text_weight_hook_path_matches_oracle():
     assert rel(got.cpu(), ref) < 0.5 * rel(plain, ref), "hooked HIP run must follow the hooked oracle, not the plain one"
     wr.restore_original_methods()
     assert all("forward" not in b.cross_attn.__dict__ for b in m.blocks)
+
+
+def test_checkpoint_directory_written_independently_loads_and_runs(tmp_path):
+    """SURVEY 8(f) rank 1, the wire formats: a checkpoint DIRECTORY whose files are built here with plain json / safetensors /
+    torch.save calls (not with the product's writer) in the layouts the reference reads - diffusers `config.json` + three
+    safetensors shards + index for the DiT (textimage2video.py:103), a `Wan2.2_VAE.pth` state dict (vae2_2.py:877-883), a T5
+    `.pth` state dict (t5.py:496) - is loaded through WanModel.from_pretrained / WanTI2V(checkpoint_dir=...) and must reproduce
+    the reference-generated goldens on the HIP path."""
+    import json
+    from safetensors.torch import save_file
+    from oracle import t5 as ot5
+    from oracle import wan_dit, wan_vae
+    from univid_amd.wan.model import WanModel
+    from univid_amd.wan.t5 import T5EncoderModel
+    from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+    g = load_golden("dit_tiny")
+    cfg = wan_dit.TINY_CFG
+    sd = wan_dit.make_state_dict(cfg, g["seed"])
+    d = tmp_path / "Wan2.2-TI2V-tiny"
+    d.mkdir()
+    # --- DiT: what diffusers' save_pretrained leaves behind (extra bookkeeping keys included)
+    json.dump({"_class_name": "WanModel", "_diffusers_version": "0.35.1", "model_type": "ti2v", "patch_size": [1, 2, 2],
+               "text_len": cfg["text_len"], "in_dim": 48, "dim": cfg["dim"], "ffn_dim": cfg["ffn_dim"], "freq_dim": 256,
+               "text_dim": cfg["text_dim"], "out_dim": 48, "num_heads": cfg["num_heads"], "num_layers": cfg["num_layers"],
+               "window_size": [-1, -1], "qk_norm": True, "cross_attn_norm": True, "eps": 1e-6}, open(d / "config.json", "w"))
+    names = sorted(sd)
+    cuts = [0, len(names) // 3, 2 * len(names) // 3, len(names)]
+    weight_map = {}
+    for i in range(3):
+        fn = f"diffusion_pytorch_model-{i + 1:05d}-of-00003.safetensors"
+        save_file({k: sd[k].contiguous() for k in names[cuts[i]:cuts[i + 1]]}, str(d / fn), metadata={"format": "pt"})
+        weight_map.update({k: fn for k in names[cuts[i]:cuts[i + 1]]})
+    json.dump({"metadata": {"total_size": sum(v.numel() * 4 for v in sd.values())}, "weight_map": weight_map},
+              open(d / "diffusion_pytorch_model.safetensors.index.json", "w"))
+    # --- VAE: a plain state dict (width-reduced topology of the golden fixture)
+    gv = load_golden("vae_small")
+    torch.save(wan_vae.make_state_dict(wan_vae.SMALL_CFG, gv["seed"]), str(d / "Wan2.2_VAE.pth"))
+    # --- T5: a plain state dict + a tokenizer directory (tiny word-level vocabulary)
+    gt = load_golden("t5_tiny")
+    tcfg = ot5.TINY_CFG
+    torch.save(ot5.make_state_dict(tcfg, int(gt["seed"])), str(d / "models_t5_tiny.pth"))
+
+    m = WanModel.from_pretrained(str(d)).to(DEV)
+    assert m.num_layers == cfg["num_layers"] and m.patch_size == (1, 2, 2)
+    with torch.no_grad():
+        one = m([g["x"].to(DEV)], g["t_one"].to(DEV), [g["ctx"].to(DEV)], 256)[0]
+    assert_model_close(one, g["out_one"], name="DiT from an independently written sharded checkpoint")
+
+    class TinyCfg(TI2VConfig):
+        text_len = 48
+        vae_kwargs = dict(c_dim=32, dec_dim=32)
+        t5_checkpoint = "models_t5_tiny.pth"
+        t5_tokenizer = "no-such-tokenizer-dir"           # absent: the text encoder stays injectable
+    pipe = WanTI2V(TinyCfg, checkpoint_dir=str(d), device=DEV)
+    assert pipe.vae is not None and pipe.text_encoder is None
+    with torch.no_grad():
+        two = pipe.model([g["x"].to(DEV)], g["t_two"].to(DEV), [g["ctx"].to(DEV)], 256)[0]
+        dec = pipe.vae.decode([gv["dec_in_0"].to(DEV)])[0]
+        enc = pipe.vae.encode([gv["enc_in_0"].to(DEV)])[0]
+    assert_model_close(two, g["out_two"], name="DiT through WanTI2V(checkpoint_dir=...)")
+    assert_f32_close(dec, gv["dec_out_0"], name="VAE decode from Wan2.2_VAE.pth")
+    assert_f32_close(enc, gv["enc_out_0"], name="VAE encode from Wan2.2_VAE.pth")
+    # T5 .pth through the reference-style wrapper (t5.py:473-513) with the tiny architecture
+    ids = torch.zeros(1, 48, dtype=torch.long)
+    ids[0, :33] = gt["ids_33"]
+    mask = (torch.arange(48) < 33).long().unsqueeze(0)
+    enc_model = T5EncoderModel(text_len=48, device=DEV, checkpoint_path=str(d / "models_t5_tiny.pth"), tokenizer=lambda texts, **kw: (ids, mask),
+                               encoder_kwargs=dict(vocab=tcfg["vocab_size"], dim=tcfg["dim"], dim_attn=tcfg["dim_attn"], dim_ffn=tcfg["dim_ffn"],
+                                                   num_heads=tcfg["num_heads"], num_layers=tcfg["num_layers"], num_buckets=tcfg["num_buckets"]))
+    out = enc_model(["a prompt"], DEV)[0].float().cpu()
+    ref = gt["out_33"].float()
+    assert out.shape == ref.shape and _rel_rms(out, ref) < 3e-3 and (out == ref).float().mean() > 0.8
+    # a directory whose shards miss a parameter must be refused, not half-loaded
+    (d / "diffusion_pytorch_model-00003-of-00003.safetensors").unlink()
+    save_file({k: sd[k].contiguous() for k in names[cuts[2]:cuts[3] - 1]}, str(d / "diffusion_pytorch_model-00003-of-00003.safetensors"))
+    with pytest.raises(RuntimeError, match="does not match"):
+        WanModel.from_pretrained(str(d))
 
 
 def test_model_errors_are_loud():
@@ -1077,10 +1209,44 @@ def test_full_size_dit_stack_equals_sequential():
 # The sharded forward must reproduce the plain forward bit for bit: GEMM rows, RMSNorm/RoPE rows and (query, head) attention
 # problems are the same arithmetic wherever they run.
 # ---------------------------------------------------------------------------------------------------------------
-def _sp_gpu_worker(rank, world, port, q):
+def _init_group(rank, world, port, nccl):
+    """gloo: the ranks share the test box's one GPU (exchanges go through the host-memory emulation of univid_amd.parallel);
+    nccl: one GPU per rank, RCCL over xGMI - the transport the product uses (runs where the box has >= `world` GPUs)."""
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if nccl:
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def _spawn(worker, world, nccl, timeout=300):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, nccl)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=timeout) for _ in procs)
+    for p in procs:
+        p.join(60)
+    return res
+
+
+def _need_gpus(n):
+    if torch.cuda.device_count() < n:
+        pytest.skip(f"needs {n} GPUs (RCCL, one device per rank); this box has {torch.cuda.device_count()}")
+
+
+def _sp_gpu_worker(rank, world, port, q, nccl=False):
+    dist = _init_group(rank, world, port, nccl)
     try:
         g = load_golden("dit_tiny")
         cfg, sd, m = _tiny_model(g["seed"], num_heads=4)
@@ -1111,26 +1277,21 @@ def _sp_gpu_worker(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_sequence_parallel_forward_is_bit_identical(world):
-    import socket
-    import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_sp_gpu_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(60)
+    res = _spawn(_sp_gpu_worker, world, nccl=False)
     assert all(ok and refused for _, ok, refused, _ in res), res
 
 
-def _cfgp_gpu_worker(rank, world, port, q):
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sequence_parallel_forward_over_rccl(world):
+    """The same check with one GPU per rank and RCCL all-to-alls / all-gathers over xGMI (parallel.py's `backend == "nccl"`
+    branches; reference distributed/ulysses.py:9-47, util.py:6-51): bit-identical to the unsharded forward on every rank."""
+    _need_gpus(world)
+    res = _spawn(_sp_gpu_worker, world, nccl=True)
+    assert all(ok and refused for _, ok, refused, _ in res), res
+
+
+def _cfgp_gpu_worker(rank, world, port, q, nccl=False):
+    dist = _init_group(rank, world, port, nccl)
     try:
         from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
         g = load_golden("sampler_tiny")
@@ -1153,27 +1314,81 @@ def _cfgp_gpu_worker(rank, world, port, q):
 def test_cfg_parallel_denoise_is_bit_identical():
     """SURVEY 8(e) intra-sample sharding: cond on rank 0, uncond on rank 1, one all-gather of the prediction per step; both ranks
     must end every step with the latent of the single-process loop, bit for bit (t2v and i2v). Two processes on the one GPU, gloo."""
-    import socket
-    import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_cfgp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(60)
+    res = _spawn(_cfgp_gpu_worker, 2, nccl=False)
     assert all(ok for _, ok, _, _ in res), res
     assert [b for _, _, b, _ in res] == ["cond", "uncond"]
 
 
-def _sp_full_worker(rank, world, port, q):
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def test_cfg_parallel_denoise_over_rccl():
+    """CFG pair on two GPUs, the prediction exchanged by an RCCL all-gather per step: bit-identical to the single-GPU loop."""
+    _need_gpus(2)
+    res = _spawn(_cfgp_gpu_worker, 2, nccl=True)
+    assert all(ok for _, ok, _, _ in res), res
+    assert [b for _, _, b, _ in res] == ["cond", "uncond"]
+
+
+def _replica_gpu_worker(rank, world, port, q, nccl=False):
+    """The metric's multi-GPU mode (bench.py --gpus N): independent samples sharded over the ranks, weights replicated,
+    ONE all-gather of the final latents; every rank must end with every sample's latent, bit-identical to denoising all samples
+    on one GPU."""
+    dist = _init_group(rank, world, port, nccl)
+    try:
+        from univid_amd import parallel
+        from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+        g = load_golden("sampler_tiny")
+        cfg, sd, m = _tiny_model(g["seed"])
+        pipe = WanTI2V(TI2VConfig, model=m, device=torch.device("cuda", torch.cuda.current_device()))
+        n = world + 1                                                  # uneven shards: the first rank owns two samples
+        gens = [torch.Generator().manual_seed(parallel.sample_seed(100, i)) for i in range(n)]
+        noises = [torch.randn(48, 4, 16, 16, generator=gg).to(DEV) for gg in gens]
+        ctxs = [[(g["ctx"] * (1 + 0.1 * i)).to(DEV)] for i in range(n)]
+        nulls = [[g["ctx_null"].to(DEV)] for _ in range(n)]
+        with torch.no_grad():
+            alone = [pipe.denoise(noises[i], ctxs[i], nulls[i], 3, g["shift"], g["guide_scale"]) for i in range(n)]
+            got = parallel.denoise_batch(pipe, noises, ctxs, nulls, 3, g["shift"], g["guide_scale"])
+        ok = len(got) == n and all(torch.equal(a, b) for a, b in zip(got, alone))
+        q.put((rank, bool(ok), str(got[0].device)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sample_replicas_and_latent_all_gather_shared_gpu():
+    res = _spawn(_replica_gpu_worker, 2, nccl=False)
+    assert all(ok for _, ok, _ in res), res
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sample_replicas_and_latent_all_gather_over_rccl(world):
+    """One GPU per rank, the all-gather of the final latents on RCCL over xGMI (the single collective of the path)."""
+    _need_gpus(world)
+    res = _spawn(_replica_gpu_worker, world, nccl=True)
+    assert all(ok for _, ok, _ in res), res
+    assert sorted(d for _, _, d in res) == sorted(f"cuda:{r}" for r in range(world))
+
+
+def test_model_on_second_gpu_without_set_device():
+    """The reference's manual model placement (`wan_gpu=1`, model_pipeline.py): a model living on cuda:1 must run there while the
+    process's current device stays cuda:0 - every launch follows the device of its tensors (univid_amd._lib.call)."""
+    _need_gpus(2)
+    g = load_golden("dit_tiny")
+    cfg, sd, m0 = _tiny_model(g["seed"])
+    from univid_amd.wan.model import WanModel
+    m1 = WanModel.from_config(dict(cfg, model_type="ti2v"))
+    m1.load_state_dict(sd)
+    m1 = m1.to("cuda:1").eval()
+    assert torch.cuda.current_device() == 0
+    with torch.no_grad():
+        a = m0([g["x"].to("cuda:0")], g["t_two"].to("cuda:0"), [g["ctx"].to("cuda:0")], 256)[0]
+        b = m1([g["x"].to("cuda:1")], g["t_two"].to("cuda:1"), [g["ctx"].to("cuda:1")], 256)[0]
+    assert b.device == torch.device("cuda:1") and torch.cuda.current_device() == 0
+    assert torch.equal(a.cpu(), b.cpu())
+    with pytest.raises(L().UnividHipError):
+        L().gemm_bf16(torch.zeros(64, 64, dtype=BF16, device="cuda:0"), torch.zeros(64, 64, dtype=BF16, device="cuda:1"), None,
+                      torch.zeros(64, 64, dtype=BF16, device="cuda:0"), 0)
+
+
+def _sp_full_worker(rank, world, port, q, nccl=False):
+    dist = _init_group(rank, world, port, nccl)
     try:
         from univid_amd.wan.model import WanModel
         from univid_amd.wan.textimage2video import TI2VConfig
@@ -1201,19 +1416,14 @@ def _sp_full_worker(rank, world, port, q):
 def test_full_size_sequence_parallel_bit_identical():
     """The bench shape (11 440 tokens, 24 heads x 128, cond+uncond stacked), one TI2V-5B-width block, 2 ranks: token shards of
     5 720, 12 heads per rank in the exchanged attention; bit-identical to the unsharded forward."""
-    import socket
-    import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_sp_full_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(60)
+    res = _spawn(_sp_full_worker, 2, nccl=False, timeout=600)
+    assert all(ok for _, ok in res), res
+
+
+def test_full_size_sequence_parallel_over_rccl():
+    """The bench shape on 2 GPUs: 8.8 MB all-to-alls per tensor over RCCL / xGMI; bit-identical to the unsharded forward."""
+    _need_gpus(2)
+    res = _spawn(_sp_full_worker, 2, nccl=True, timeout=600)
     assert all(ok for _, ok in res), res
 
 

@@ -27,6 +27,7 @@ SIGNATURES = {
     "uv_gemm_f32_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _P],
     "uv_flash_attn_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "uv_flash_attn_f16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
+    "uv_flash_attn_kernel_name": [_I, _I, _L, _L, _I, _c.c_char_p, _I],
     "uv_transpose_16": [_P, _L, _P, _L, _I, _I, _I, _P],
     "uv_cast_f32_to16": [_P, _P, _L, _I, _P],
     "uv_cast_16_to_f32": [_P, _P, _L, _I, _P],
@@ -235,6 +236,17 @@ def flash_attn(q, k, vt, out, Lq, Lk, H, D, scale, batch=1):
     call("uv_flash_attn_f16" if f16 else "uv_flash_attn_bf16", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(vt), vt.stride(0), ptr(out), out.stride(0),
          batch, Lq, Lk, H, D, float(scale), stream_ptr(), flops=4 * batch * Lq * Lk * H * D)
     return out
+
+
+def attn_kernel_name(Lq, Lk, D, batch=1, H=None, f16=False):
+    """Name of the kernel `flash_attn` dispatches for this geometry (dense [tokens, H*D] rows as the DiT uses them)."""
+    H = H or 1
+    buf = ctypes.create_string_buffer(96)
+    ldvt = (batch - 1) * Lk + (Lk + 63) // 64 * 64
+    rc = load().uv_flash_attn_kernel_name(Lk, D, H * D, ldvt, int(f16), buf, 96)
+    if rc != 0:
+        raise UnividHipError(load().uv_last_error().decode())
+    return buf.value.decode()
 
 
 def layernorm_mod(x, out, L, C, eps, mode=0, tab=None, shift_off=0, scale_off=0, tid=None, w=None, b=None,

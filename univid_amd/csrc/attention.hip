@@ -7,10 +7,10 @@
 //           WanSelfAttention.forward model.py:145-150 and WanCrossAttention.forward model.py:175.
 //
 // Three kernels share the operand layouts, LDS images and arithmetic below:
-//   flash_attn_fwd12_kernel  head_dim 128, bf16, Lk >= 2048 (self-attention): one 12-wave workgroup per CU, 384 queries per K/V^T stream
+//   flash_attn_fwd12_kernel  head_dim 128, bf16, Lk >= 2048 (self-attention): one 12-wave workgroup per CU, up to 384 queries per K/V^T stream
 //   flash_attn_fwd3_kernel   head_dim 128, bf16, shorter Lk (cross-attention): three 4-wave workgroups per CU (48 KiB LDS, <= 168 registers)
-//   flash_attn_fwd_kernel    head_dim 64 / fp16 operands / very large leading dimensions: two 4-wave workgroups per CU (the first design;
-//                            also carries the QB = 2 one-wave-per-SIMD experiment and the stamped diagnostic build)
+//   flash_attn_fwd_kernel    head_dim 64 / fp16 operands / very large leading dimensions: two 4-wave workgroups per CU (the first design)
+// attn_select() is the ONE place that decides which of them serves a call (uv_flash_attn_kernel_name reports it).
 // Common structure (one wave = 32 queries of one head; staged KV tile = 64 keys):
 //   * swapped product S^T = K.Q^T with v_mfma_f32_32x32x16_bf16: the query sits on the lane, its
 //     32 keys of a tile sit in the 16 accumulator registers of both half-waves, so the softmax row
@@ -27,10 +27,9 @@
 //     is computed; one vmcnt(0) + one barrier per tile.
 //   * the softmax reference maximum moves only when a row maximum outgrows it by more than 2^UV_ATT_DEFER.
 //   * independent samples are one launch: q/k/out rows and V^T COLUMNS stacked per sample.
-// Template parameters: D head_dim (128 / 64), NW waves per workgroup, STAMP in-kernel cycle stamps (diagnostic entry
-// uvdbg_flash_attn_stamps), QB = 2 the experimental one-wave-per-SIMD 64-queries-per-wave form (UV_ATTN_QB=2, see DESIGN
-// section 9), SGB fragment reads scheduled 6 ahead of their MFMA.
+// Template parameters of flash_attn_fwd_kernel: D head_dim (128 / 64), SGB fragment reads scheduled 6 ahead of their MFMA, F16 IEEE fp16 operands.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -54,16 +53,13 @@ __device__ __forceinline__ int perm23(int i) {  // swap bits 2 and 3
     return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
 
-// D = head_dim (128 for TI2V-5B; 64 for the reference's CPU-runnable tiny config).
-// NW = waves per workgroup: 8 (256 queries, 1 workgroup per CU) or 4 (128 queries, 2 workgroups per CU: the two waves
-// that share a SIMD then belong to DIFFERENT workgroups, are not re-aligned by a common barrier every tile, and drift
-// into complementary phases - one in its MFMA cluster while the other does softmax VALU work).
-// QB = 32-query blocks per wave. QB = 2 with NW = 4 is the one-wave-per-SIMD form: the wave owns the SIMD's whole 512-entry
-// register file, every K / V^T fragment read from LDS and every LDS-DMA piece serves 64 queries instead of 32, and the
-// softmax VALU work of one block has the other block's MFMAs to hide behind inside the same instruction stream.
-template <int D, int NW, bool STAMP = false, int QB = 1, bool SGB = false, bool F16 = false>
-__global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kernel(AttnArgs p, unsigned long long* stamps = nullptr) {
-    static_assert(!(F16 && QB == 2), "the fp16 operand form is built for the default (QB = 1) structure only");
+// D = head_dim (128 for TI2V-5B; 64 for the reference's CPU-runnable tiny config and the SigLIP2 ranker).
+// 4 waves x 32 queries per workgroup, 2 workgroups per CU: the two waves that share a SIMD then belong to DIFFERENT workgroups, are
+// not re-aligned by a common barrier every tile, and drift into complementary phases - one in its MFMA cluster while the other
+// does softmax VALU work.
+template <int D, bool SGB = false, bool F16 = false>
+__global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs p) {
+    constexpr int NW = 4;
     constexpr int NT = NW * 64;
     constexpr int KROW = 2 * D;                 // bytes per K row in LDS (256 or 128)
     constexpr int KCH = D / 8;                  // 16-B chunks per K row
@@ -72,7 +68,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
     constexpr int K_BYTES = UV_ATT_KV * KROW;   // 16 KiB at D=128
     constexpr int V_BYTES = D * 128;            // 16 KiB at D=128
     constexpr int STAGE = K_BYTES + V_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[QB == 2 ? 2 * K_BYTES + 3 * V_BYTES : 2 * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -90,17 +86,16 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
         p.vt += (long)b * p.Lk;
         p.out += b * p.Lq * p.ldo;
     }
-    const int q0w = qb * (NW * QB * UV_ATT_QW) + wave * (QB * UV_ATT_QW);
+    const int q0w = qb * (NW * UV_ATT_QW) + wave * UV_ATT_QW;
     const long hcol = (long)head * D;
 
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane (r,h) holds Q[q0w+32b+r][16kk+8h .. +7]
-    bf16x8 qf[QB][NKK];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        const int qrow = min(q0w + 32 * b + r, p.Lq - 1);
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane (r,h) holds Q[q0w+r][16kk+8h .. +7]
+    bf16x8 qf[NKK];
+    {
+        const int qrow = min(q0w + r, p.Lq - 1);
         const bf16_t* qp = p.q + (long)qrow * p.ldq + hcol + 8 * h;
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) qf[b][kk] = *(const bf16x8*)(qp + 16 * kk);
+        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
     }
 
     // ---- staging: K and V^T tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction,
@@ -180,282 +175,34 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
     const int v_row_off = K_BYTES + r * 128;
     const int v_key = (r >> 1) & 7;
 
-    f32x16 oacc[QB][ND];
-    float m_run[QB];  // running max of raw scores (both half-waves hold the same value)
-    float l_run[QB];  // this half-wave's partial row sum
+    f32x16 oacc[ND];
 #pragma unroll
-    for (int b = 0; b < QB; ++b) {
+    for (int d = 0; d < ND; ++d)
 #pragma unroll
-        for (int d = 0; d < ND; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[b][d][e] = 0.f;
-        m_run[b] = -INFINITY;
-        l_run[b] = 0.f;
-    }
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    float m_run = -INFINITY;  // running reference maximum of the raw scores (both half-waves hold the same value)
+    float l_run = 0.f;        // this half-wave's partial row sum
 
     const int nt = (p.Lk + UV_ATT_KV - 1) / UV_ATT_KV;
     const int nt_full = p.Lk / UV_ATT_KV;
-    if constexpr (QB == 2) {
-        char* kb = smem;
-        char* vb = smem + 2 * K_BYTES;
-#pragma unroll
-        for (int i = 0; i < K_INSTR; ++i) {
-            const bf16_t* src = ksrc[i] + (long)min(krow[i], p.Lk - 1) * p.ldk;
-            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(kb + (i * NW + wave_u) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < V_INSTR; ++i) {
-            const bf16_t* src = vsrc[i];
-            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(vb + (i * NW + wave_u) * 1024), 16, 0, 0);
-        }
-    } else {
-        fetch(0, 0);
-    }
+    fetch(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // Pin "every prologue load has landed" BEFORE the loop: vmcnt retires in order, so if the compiler has to assume
     // the Q fragment loads may still be in flight at the loop header it guards their first use inside the loop with
     // vmcnt(1)/vmcnt(0) - which in steady state waits for the K/V prefetch issued a few instructions earlier and
     // exposes a full L2/HBM latency in every tile (seen in the ISA; ~1000 cycles of a 4500-cycle tile).
 #pragma unroll
-    for (int b = 0; b < QB; ++b)
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[b][kk]));
+    for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]));
     __syncthreads();
 
     // One KV tile. MASKED is a compile-time flag so that the main loop carries no masking code at all (only the ragged
     // last tile is instantiated with it).
-    // diagnostic build only (STAMP): per-segment cycle sums [qk, softmax, pv, commit, barrier] per wave
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = 0;
-    auto stamp = [&](int which) {
-        if (STAMP) {
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long tnow;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (which >= 0) seg[which] += tnow - tprev;
-            tprev = tnow;
-        }
-    };
-    // ---- one-wave-per-SIMD form (QB == 2): the two 32-query blocks A and B of the wave run half a tile apart so that
-    // each block's softmax VALU work has the other block's MFMAs to hide behind, inside ONE instruction stream:
-    //     QK_A | QK_B + softmax_A | PV_A + softmax_B | PV_B
-    // The rescale decision (a rare branch, see below) is taken before the mixed regions so that each of them is one
-    // basic block the scheduler can interleave.
-    // Row sums by MFMA (QB == 2 path): one more accumulator tile per block whose A operand is all ones, so
-    // lacc[b][*] = sum over keys of the bf16 P values (every register of a lane holds the same sum). It replaces 32
-    // v_add_f32 per block and tile - the VALU pipe, not the matrix pipe, is the busy one in the mixed regions.
-    f32x16 lacc[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) lacc[b][e] = 0.f;
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-    // Software pipeline of the QB == 2 form. Block B runs one tile behind block A, so that every group of MFMAs has
-    // softmax VALU work of the OTHER block to hide (one wave per SIMD: nothing else would):
-    //     step 1   MFMA  S_A(t)  = K(t) Q_A             VALU  P_B(t-1) = exp2(S_B(t-1) ...)
-    //     step 2   MFMA  O_B    += V(t-1) P_B(t-1)  (1st half)      row max of S_A(t)      -> reference-maximum decision A
-    //     step 3   MFMA  O_B (2nd half), S_B(t) = K(t) Q_B          P_A(t) = exp2(S_A(t) ...)
-    //     step 4   MFMA  O_A    += V(t) P_A(t)      (1st half)      row max of S_B(t)      -> decision B
-    //     step 5   MFMA  O_A (2nd half)
-    // V tiles therefore live for two iterations (3-deep V ring, 2-deep K ring). Tile -1 is a dummy: S_B(-1) = -inf
-    // gives P = 0, multiplied into V(0)'s (finite) fragments.
-    f32x16 sB[2];      // S_B of the previous tile
-    float mnegB = 0.f;
-    bf16x8 pB[2][2];
-#pragma unroll
-    for (int T = 0; T < 2; ++T)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sB[T][e] = -INFINITY;
-    const char* const vring = smem + 2 * K_BYTES;
-    int vcur = 0, vprev = 0;   // V ring slots of tile t and t-1
-    auto rowmax = [&](f32x16 (&s_)[2], int kv0, bool masked) -> float {
-        if (masked) {
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (kv0 + perm23(i) >= p.Lk) s_[T][e] = -INFINITY;
-                }
-        }
-        float mt = s_[0][0];
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mt = fmaxf(mt, s_[T][e]);
-        const unsigned u = __builtin_bit_cast(unsigned, mt);
-        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
-    };
-    // The O and l accumulators live in the accumulator half of the register file, which no VALU instruction can touch,
-    // so a rescale is three instructions per register; with the deferred reference maximum (UV_ATT_DEFER) it practically
-    // happens on the first tile only. Returns -m_ref * scale.
-    auto decide = [&](int b, float mt) -> float {
-        const float grow = (mt - m_run[b]) * p.scale_log2;      // +inf on the first tile (m_run = -inf)
-        if (__any(grow > UV_ATT_DEFER)) {
-            const float m_new = fmaxf(m_run[b], mt);
-            const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * p.scale_log2);
-            float chain = alpha;   // orders the statements below (asm statements are opaque to the scheduler)
-#pragma unroll
-            for (int d = 0; d <= ND; ++d)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float tmp;
-                    // leading nops: the last MFMA that wrote this accumulator must have retired (16-pass XDL ->
-                    // accvgpr read); trailing nop: accvgpr write -> MFMA source
-                    if (d < ND)
-                        asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\t"
-                                     "v_accvgpr_write_b32 %0, %1\n\ts_nop 1"
-                                     : "+a"(oacc[b][d][e]), "=&v"(tmp), "+v"(chain));
-                    else
-                        asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\t"
-                                     "v_accvgpr_write_b32 %0, %1\n\ts_nop 1"
-                                     : "+a"(lacc[b][e]), "=&v"(tmp), "+v"(chain));
-                }
-            asm volatile("" : "+v"(chain));
-            m_run[b] = m_new;
-        }
-        return -m_run[b] * p.scale_log2;
-    };
-    auto expP = [&](f32x16 (&s_)[2], float mneg, bf16x8 (&p_)[2][2]) {
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    p_[T][s2][j] = (__bf16)__builtin_amdgcn_exp2f(__builtin_fmaf(s_[T][8 * s2 + j], p.scale_log2, mneg));
-    };
-    // keeps P from being sunk below the next rescale branch by the IR optimiser (away from the MFMAs it should overlap)
-    auto pinP = [&](bf16x8 (&p_)[2][2]) {
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : "+v"(p_[T][s2]));
-    };
-    auto qk2 = [&](const char* kbase, int b, f32x16 (&s_)[2]) {
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s_[T][e] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const bf16x8 kf = *(const bf16x8*)(kbase + T * 32 * KROW + k_row_off + (((2 * kk + h) ^ k_key) << 4));
-                s_[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][kk], s_[T], 0, 0, 0);
-            }
-        }
-    };
-    // half of O^T += V^T P^T: d tiles {2*half, 2*half+1}; the row-sum tile (A operand = ones) rides with the second half
-    auto pv2 = [&](const char* vbase, int b, bf16x8 (&p_)[2][2], int half) {
-#pragma unroll
-        for (int dd = 0; dd < ND / 2; ++dd) {
-            const int d = half * (ND / 2) + dd;
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 vf = *(const bf16x8*)(vbase + d * 32 * 128 + (v_row_off - K_BYTES) + (((4 * T + 2 * s2 + h) ^ v_key) << 4));
-                    oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, p_[T][s2], oacc[b][d], 0, 0, 0);
-                }
-        }
-        if (half == 1) {
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-                    lacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p_[T][s2], lacc[b], 0, 0, 0);
-        }
-    };
-    auto fetch2 = [&](int kv0, int kslot, int vslot) {
-        char* kb = smem + kslot * K_BYTES;
-        char* vb = smem + 2 * K_BYTES + vslot * V_BYTES;
-#pragma unroll
-        for (int i = 0; i < K_INSTR; ++i) {
-            const int kr = min(kv0 + krow[i], p.Lk - 1);
-            const bf16_t* src = ksrc[i] + (long)kr * p.ldk;
-            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(kb + (i * NW + wave_u) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < V_INSTR; ++i) {
-            const bf16_t* src = vsrc[i] + kv0;
-            __builtin_amdgcn_global_load_lds(src, (lds_void_a*)(vb + (i * NW + wave_u) * 1024), 16, 0, 0);
-        }
-    };
-    auto tile2 = [&](int t, auto masked_tag) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        const int kv0 = t * UV_ATT_KV;
-        const char* kbase = smem + (t & 1) * K_BYTES;
-        const char* vb_cur = vring + vcur * V_BYTES;
-        const char* vb_prev = vring + vprev * V_BYTES;
-        const int vnext = vcur == 2 ? 0 : vcur + 1;
-        if (t + 1 < nt) fetch2(kv0 + UV_ATT_KV, (t + 1) & 1, vnext);
-        // Q is only ever an MFMA source: keep it in the accumulator half of the register file (legal for MFMA A/B operands)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+a"(qf[b][kk]));
-        f32x16 sA[2];
-        bf16x8 pA[2][2];
-        stamp(-1);
-        // step 1
-        qk2(kbase, 0, sA);
-        expP(sB, mnegB, pB);
-        pinP(pB);
-        __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { asm volatile("" ::"v"(sA[1][15])); }
-        stamp(0);
-        // step 2
-        pv2(vb_prev, 1, pB, 0);
-        const float mtA = rowmax(sA, kv0, MASKED);
-        __builtin_amdgcn_sched_barrier(0);
-        const float mnegA = decide(0, mtA);
-        __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { asm volatile("" ::"v"(mnegA)); }
-        stamp(1);
-        // step 3
-        pv2(vb_prev, 1, pB, 1);
-        qk2(kbase, 1, sB);
-        expP(sA, mnegA, pA);
-        pinP(pA);
-        __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { asm volatile("" ::"v"(sB[1][15])); }
-        stamp(2);
-        // step 4
-        pv2(vb_cur, 0, pA, 0);
-        const float mtB = rowmax(sB, kv0, MASKED);
-        __builtin_amdgcn_sched_barrier(0);
-        mnegB = decide(1, mtB);
-        __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { asm volatile("" ::"v"(mnegB)); }
-        stamp(3);
-        // step 5
-        pv2(vb_cur, 0, pA, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { asm volatile("" ::"a"(oacc[0][ND - 1][15])); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        stamp(4);
-        vprev = vcur;
-        vcur = vnext;
-    };
-    // drains block B's last tile after the loop
-    auto tail2 = [&]() {
-        const char* vb_prev = vring + vprev * V_BYTES;
-        expP(sB, mnegB, pB);
-        pv2(vb_prev, 1, pB, 0);
-        pv2(vb_prev, 1, pB, 1);
-    };
-
     // FETCH: 1 = the next tile is a full one (running pointers, no branch: the LDS-DMA instructions then sit in the same
     // scheduling region as the QK MFMAs and are dealt out between them), 0 = decide at run time (last full tile / ragged tile)
     auto tile = [&](int t, auto masked_tag, auto fetch_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr bool FETCH_FAST = decltype(fetch_tag)::value;
         const int kv0 = t * UV_ATT_KV;
-        stamp(-1);
         const char* base = smem + (t & 1) * STAGE;
         // other buffer: last read in tile t-1, fenced by its barrier
         if constexpr (FETCH_FAST) {
@@ -464,25 +211,21 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
             if (t + 1 < nt_full) fetch_next_full((t + 1) & 1);
             else if (t + 1 < nt) fetch(kv0 + UV_ATT_KV, (t + 1) & 1);   // the ragged last tile: clamped rows
         }
-        stamp(5);
 
-        // ---- S^T = K . Q^T  (two 32-key tiles) for every 32-query block of the wave
-        f32x16 sacc[QB][2];
+        // ---- S^T = K . Q^T  (two 32-key tiles)
+        f32x16 sacc[2];
 #pragma unroll
-        for (int b = 0; b < QB; ++b)
+        for (int T = 0; T < 2; ++T) {
 #pragma unroll
-            for (int T = 0; T < 2; ++T) {
+            for (int e = 0; e < 16; ++e) sacc[T][e] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[b][T][e] = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) {
-                    const bf16x8 kf =
-                        *(const bf16x8*)(base + T * 32 * KROW + k_row_off + (((2 * kk + h) ^ k_key) << 4));
-                    sacc[b][T] = mfma_32x32x16<F16>(kf, qf[b][kk], sacc[b][T]);
-                }
+            for (int kk = 0; kk < NKK; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(base + T * 32 * KROW + k_row_off + (((2 * kk + h) ^ k_key) << 4));
+                sacc[T] = mfma_32x32x16<F16>(kf, qf[kk], sacc[T]);
             }
+        }
 
-        if constexpr (SGB && D == 128 && QB == 1) {   // fragment reads 6 ahead of the MFMA that consumes them
+        if constexpr (SGB && D == 128) {   // fragment reads 6 ahead of the MFMA that consumes them
             __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
             for (int i_ = 0; i_ < 10; ++i_) {
@@ -492,10 +235,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (STAMP) { asm volatile("" ::"v"(sacc[0][0][0]), "v"(sacc[QB - 1][1][15])); }
-        stamp(0);
-#pragma unroll
-        for (int b = 0; b < QB; ++b) {
+        {
             // ---- mask the ragged last tile with the TRUE key index of each accumulator row
             if (MASKED) {
 #pragma unroll
@@ -503,67 +243,38 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int i = 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (kv0 + perm23(i) >= p.Lk) sacc[b][T][e] = -INFINITY;
+                        if (kv0 + perm23(i) >= p.Lk) sacc[T][e] = -INFINITY;
                     }
             }
 
             // ---- online softmax (query on the lane)
-            float mt = sacc[b][0][0];
+            float mt = sacc[0][0];
 #pragma unroll
             for (int T = 0; T < 2; ++T)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sacc[b][T][e]);
+                for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sacc[T][e]);
             {   // the other half-wave's maximum: v_permlane32_swap (one VALU op) instead of a ds_bpermute round trip
                 const unsigned u = __builtin_bit_cast(unsigned, mt);
                 const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
                 mt = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
             }
             float mneg;
-            if constexpr (QB == 1) {
-                // The reference maximum m_run moves only when some row's maximum outgrows it by more than 2^UV_ATT_DEFER in
-                // the exponent domain (then P <= 2^UV_ATT_DEFER instead of <= 1 until the next move; P, l and O share one
-                // scale and bf16 / f32 relative precision is scale-invariant). With the exact running maximum about half
-                // of all tiles of a long sequence still see a new maximum in SOME row of the wave and pay the O rescale.
-                const float grow = (mt - m_run[b]) * p.scale_log2;      // +inf on the first tile (m_run = -inf)
-                if (__any(grow > UV_ATT_DEFER)) {
-                    const float m_new = fmaxf(m_run[b], mt);
-                    const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * p.scale_log2);
-                    l_run[b] *= alpha;
+            // The reference maximum m_run moves only when some row's maximum outgrows it by more than 2^UV_ATT_DEFER in
+            // the exponent domain (then P <= 2^UV_ATT_DEFER instead of <= 1 until the next move; P, l and O share one
+            // scale and bf16 / f32 relative precision is scale-invariant). With the exact running maximum about half
+            // of all tiles of a long sequence still see a new maximum in SOME row of the wave and pay the O rescale.
+            const float grow = (mt - m_run) * p.scale_log2;      // +inf on the first tile (m_run = -inf)
+            if (__any(grow > UV_ATT_DEFER)) {
+                const float m_new = fmaxf(m_run, mt);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+                l_run *= alpha;
 #pragma unroll
-                    for (int d = 0; d < ND; ++d)
+                for (int d = 0; d < ND; ++d)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) oacc[b][d][e] *= alpha;
-                    m_run[b] = m_new;
-                }
-                mneg = -m_run[b] * p.scale_log2;
-            } else {
-                // One wave per SIMD: the O accumulators live in the accumulator half of the register file, which no VALU
-                // instruction can touch, so a rescale is three instructions per register. It is therefore deferred: the
-                // reference maximum moves only when a row's maximum outgrows it by more than 2^8 in the exponent domain
-                // (P <= 256 instead of <= 1; P, l and O all stay at the same scale, bf16/f32 relative precision is
-                // scale-invariant), which after the first tile practically never happens.
-                const float grow = (mt - m_run[b]) * p.scale_log2;      // +inf on the first tile (m_run = -inf)
-                if (__any(grow > UV_ATT_DEFER)) {
-                    const float m_new = fmaxf(m_run[b], mt);
-                    const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * p.scale_log2);
-                    l_run[b] *= alpha;
-                    float chain = alpha;   // orders the statements below (asm statements are opaque to the scheduler)
-#pragma unroll
-                    for (int d = 0; d < ND; ++d)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            float tmp;
-                            // leading nops: the last MFMA that wrote this accumulator must have retired (16-pass XDL ->
-                            // accvgpr read); trailing nop: accvgpr write -> MFMA source
-                            asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\t"
-                                         "v_accvgpr_write_b32 %0, %1\n\ts_nop 1"
-                                         : "+a"(oacc[b][d][e]), "=&v"(tmp), "+v"(chain));
-                        }
-                    asm volatile("" : "+v"(chain));
-                    m_run[b] = m_new;
-                }
-                mneg = -m_run[b] * p.scale_log2;
+                    for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+                m_run = m_new;
             }
+            mneg = -m_run * p.scale_log2;
             float psum = 0.f;
             bf16x8 pf[2][2];
 #pragma unroll
@@ -572,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][T][8 * s + j], p.scale_log2, mneg));
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[T][8 * s + j], p.scale_log2, mneg));
                         psum += pv;
                         if constexpr (F16) {   // fp16 bits carried in the bf16x8 container (P <= 2^UV_ATT_DEFER fits fp16 easily)
                             bf16_t bits = out16<true>(pv);
@@ -581,12 +292,10 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
                             pf[T][s][j] = (__bf16)pv;
                         }
                     }
-            l_run[b] += psum;
-            if (STAMP) { asm volatile("" ::"v"(pf[1][1])); }
-            if (b == QB - 1) stamp(1);
+            l_run += psum;
 
             // ---- O^T += V^T . P^T
-            if constexpr (SGB && D == 128 && QB == 1) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SGB && D == 128) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int d = 0; d < ND; ++d)
 #pragma unroll
@@ -595,11 +304,11 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
                     for (int s = 0; s < 2; ++s) {
                         const bf16x8 vf =
                             *(const bf16x8*)(base + d * 32 * 128 + v_row_off + (((4 * T + 2 * s + h) ^ v_key) << 4));
-                        oacc[b][d] = mfma_32x32x16<F16>(vf, pf[T][s], oacc[b][d]);
+                        oacc[d] = mfma_32x32x16<F16>(vf, pf[T][s], oacc[d]);
                     }
         }
 
-        if constexpr (SGB && D == 128 && QB == 1) {
+        if constexpr (SGB && D == 128) {
             __builtin_amdgcn_sched_group_barrier(0x100, 6, 1);
 #pragma unroll
             for (int i_ = 0; i_ < 10; ++i_) {
@@ -609,44 +318,28 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void flash_attn_fwd_kerne
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (STAMP) { asm volatile("" ::"v"(oacc[QB - 1][ND - 1][15])); }
-        stamp(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of tile t+1 has landed in LDS
-        stamp(3);
         __syncthreads();
-        stamp(4);
     };
 
-    if constexpr (QB == 2) {
-        for (int t = 0; t < nt_full; ++t) tile2(t, std::false_type{});
-        if (nt_full < nt) tile2(nt_full, std::true_type{});
-        tail2();
-    } else {
-        for (int t = 0; t + 1 < nt_full; ++t) tile(t, std::false_type{}, std::true_type{});
-        if (nt_full > 0) tile(nt_full - 1, std::false_type{}, std::false_type{});
-        if (nt_full < nt) tile(nt_full, std::true_type{}, std::false_type{});
-    }
+    for (int t = 0; t + 1 < nt_full; ++t) tile(t, std::false_type{}, std::true_type{});
+    if (nt_full > 0) tile(nt_full - 1, std::false_type{}, std::false_type{});
+    if (nt_full < nt) tile(nt_full, std::true_type{}, std::false_type{});
 
-    if (STAMP && stamps && lane == 0) {
-        unsigned long long* dst = stamps + ((long)blockIdx.x * NW + wave) * 6;
-        for (int i = 0; i < 6; ++i) dst[i] = seg[i];
-    }
     // ---- finish: combine the two half-wave sums, normalise, store bf16 rows
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        float l_half = l_run[b];
-        if constexpr (QB == 2) l_half = lacc[b][0];   // MFMA row sums: already complete over all keys (no half-wave split)
-        const float l_tot = QB == 2 ? l_half : l_half + __shfl_xor(l_half, 32, 64);
+    {
+        float l_half = l_run;
+        const float l_tot = l_half + __shfl_xor(l_half, 32, 64);
         const float inv = 1.0f / l_tot;
-        const int q = q0w + 32 * b + r;
+        const int q = q0w + r;
         if (q < p.Lq) {
             bf16_t* op = p.out + (long)q * p.ldo + hcol + 4 * h;
 #pragma unroll
             for (int d = 0; d < ND; ++d)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    u32x2 o = {pack16_2<F16>(oacc[b][d][4 * g + 0] * inv, oacc[b][d][4 * g + 1] * inv),
-                               pack16_2<F16>(oacc[b][d][4 * g + 2] * inv, oacc[b][d][4 * g + 3] * inv)};
+                    u32x2 o = {pack16_2<F16>(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv),
+                               pack16_2<F16>(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv)};
                     *(u32x2*)(op + 32 * d + 8 * g) = o;
                 }
         }
@@ -940,11 +633,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Long key sequences (default for Lk >= 2048; UV_ATTN_W3=1 keeps the 4-wave form): ONE 12-wave workgroup per CU (384 queries, three
-// waves per SIMD) sharing each K / V^T tile: a third of the L2 -> LDS traffic and 2-3 instead of 8 LDS-DMA pieces per wave and tile.
-// Bit-identical to flash_attn_fwd3_kernel (same per-wave arithmetic). Removing its barrier (timing probe) gains 0.6 %. Staging as in the two-waves kernel (K and
-// V^T double-buffered, tile t+1 requested at the top of tile t, ONE vmcnt(0) + barrier per tile), compute body and register
-// diet of flash_attn_fwd3_kernel (32-key halves, SGPR-base DMA, immediates for the buffer parity).
+// Long key sequences (Lk >= 2048): ONE 12-wave workgroup per CU (up to 384 queries, three waves per SIMD) sharing each K / V^T
+// tile: a third of the L2 -> LDS traffic and 2-3 instead of 8 LDS-DMA pieces per wave and tile. Bit-identical to
+// flash_attn_fwd3_kernel (same per-wave arithmetic). Staging as in the two-waves kernel (K and V^T double-buffered, tile t+1
+// requested at the top of tile t, ONE vmcnt(0) + barrier per tile), compute body and register diet of flash_attn_fwd3_kernel
+// (32-key halves, SGPR-base DMA, immediates for the buffer parity).
+// BALANCED QUERY BLOCKS: a (sample, head) has NWU = ceil(Lq / 32) wave-units of 32 queries. Cutting it into ceil(NWU / 12) blocks
+// of 12 waves gives, at the DiT's shape (2 x 24 heads x 358 units), 1 440 workgroups = 5.6 rounds of 256 CUs: the sixth round
+// runs on 62 % of the chip. The host instead picks the block count per head (attn12_blocks) so that the workgroups fill whole
+// rounds - 32 blocks of 11 or 12 units there, 1 536 workgroups = 6 full rounds - and block j owns the units
+// [j NWU / nblk, (j+1) NWU / nblk). All 12 waves of a workgroup stage K / V^T tiles and take every barrier; waves beyond the
+// block's unit count are LOADER-ONLY (no QK / softmax / PV), which leaves their SIMD two compute waves instead of three - and a
+// wave's tile chain is latency-bound, so those run faster. Per-query arithmetic does not depend on the cut: results are
+// bit-identical for any block count.
 // ------------------------------------------------------------------------------------------------------------------------
 template <int AHEAD = 3, bool XCD = true>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void flash_attn_fwd12_kernel(AttnArgs p) {
@@ -974,7 +675,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         p.vt += (long)b * p.Lk;
         p.out += b * p.Lq * p.ldo;
     }
-    const int q0w = qb * (NW * UV_ATT_QW) + wave_u * UV_ATT_QW;
+    // balanced cut: block qb of this head owns the 32-query units [u0, u1), u1 - u0 <= 12
+    const int nwu = (p.Lq + UV_ATT_QW - 1) / UV_ATT_QW;
+    const int u0 = (int)((long)qb * nwu / p.q_blocks), u1 = (int)((long)(qb + 1) * nwu / p.q_blocks);
+    const bool compute_wave = wave_u < u1 - u0;
+    const int q0w = (u0 + wave_u) * UV_ATT_QW;
     const long hcol = (long)head * D;
 
     bf16x8 qf[NKK];
@@ -1058,6 +763,19 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(vaddr[i >> 1][i & 1]));
     asm volatile("" : "+v"(koff), "+v"(voff));
     __syncthreads();
+
+    if (!compute_wave) {
+        // loader-only wave: its share of every tile's LDS-DMA pieces and every barrier, nothing else
+        for (int t = 0; t < nt; ++t) {
+            vbase += 2 * UV_ATT_KV;
+            kbase += kstep;
+            if (t + 1 < nt_full) fetch_full(kbase, vbase, (t & 1) ^ 1);
+            else if (t + 1 < nt) fetch_clamped((t + 1) * UV_ATT_KV, vbase, (t & 1) ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
 
     auto tile = [&](int t, auto masked_tag, auto next_tag, auto par_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
@@ -1185,129 +903,98 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
-extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
-                                  void* out, long ldo, int batch, int Lq, int Lk, int H, int head_dim,
-                                  float softmax_scale, void* stream) {
-    UV_CHECK_ARG(q && k && vt && out, "uv_flash_attn_bf16: null pointer");
-    UV_CHECK_ARG(head_dim == 128 || head_dim == 64, "uv_flash_attn_bf16: head_dim %d unsupported (64 or 128)", head_dim);
-    UV_CHECK_ARG(Lq > 0 && Lk > 0 && H > 0 && batch > 0, "uv_flash_attn_bf16: bad shape B=%d Lq=%d Lk=%d H=%d", batch, Lq, Lk, H);
-    UV_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0,
-                 "uv_flash_attn_bf16: leading dimensions must be multiples of 8 elements");
+// ---- kernel selection: the ONE place that decides which kernel serves a call ------------------------------------------------
+enum AttnKernel { ATT_FWD12 = 0, ATT_FWD3 = 1, ATT_FWD_D128 = 2, ATT_FWD_D64 = 3 };
+static const char* const kAttnKernelName[] = {"flash_attn_fwd12_kernel", "flash_attn_fwd3_kernel", "flash_attn_fwd_kernel<128>",
+                                              "flash_attn_fwd_kernel<64>"};
+
+static AttnKernel attn_select(int Lk, int head_dim, long ldk, long ldvt, bool f16) {
+    if (head_dim != 128) return ATT_FWD_D64;
+    // fwd12 / fwd3 address their LDS-DMA pieces with 32-bit lane offsets from a uniform base
+    if (f16 || 128 * ldvt >= (1L << 30) || 64 * ldk >= (1L << 30)) return ATT_FWD_D128;
+    // long key sequences: one 12-wave workgroup per CU shares each K / V^T tile among up to 384 queries (a third of the L2 -> LDS
+    // traffic; -2.8 % on the self-attention launches); short ones (cross-attention, Lk = 512: prologue and last round weigh
+    // more) keep the 4-wave workgroups (the 12-wave form is 24 % slower there)
+    return Lk >= 2048 ? ATT_FWD12 : ATT_FWD3;
+}
+
+// Query blocks per (sample, head) of flash_attn_fwd12_kernel: at least ceil(NWU / 12) (a workgroup computes at most 12 units of 32
+// queries); more when that fills whole rounds of CUs. Cost model = rounds of workgroups x time of one workgroup, where a
+// workgroup with w compute waves takes t(w) = 1 + 0.095 (w - 8) for w >= 8 (measured: 12 waves per CU deliver 1.085x the
+// throughput of 8, i.e. t(12) / t(8) = 1.38) and t = 1 below (one or two waves per SIMD run the same latency-bound chain).
+// UV_ATTN12_BLOCKS (developer knob) overrides the choice, e.g. to A/B against the ceil(NWU / 12) cut.
+static int attn12_blocks(int Lq, int heads_total) {
+    const int nwu = (Lq + UV_ATT_QW - 1) / UV_ATT_QW, ncu = uv_num_cus();
+    const int nb_min = (nwu + 11) / 12;
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("UV_ATTN12_BLOCKS"); forced = e ? atoi(e) : 0; }
+    if (forced >= nb_min && forced <= nwu) return forced;
+    int best = nb_min;
+    double best_cost = 1e30;
+    for (int nb = nb_min; nb <= nwu && nb <= 2 * nb_min; ++nb) {
+        const long wgs = (long)nb * heads_total;
+        const double rounds = (double)((wgs + ncu - 1) / ncu);
+        const double w = (double)nwu / nb;
+        const double cost = rounds * (w > 8.0 ? 1.0 + 0.095 * (w - 8.0) : 1.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = nb; }
+    }
+    return best;
+}
+
+// Name of the kernel uv_flash_attn_bf16 / _f16 dispatches for this problem (bench.py labels its roofline line with it).
+extern "C" int uv_flash_attn_kernel_name(int Lk, int head_dim, long ldk, long ldvt, int f16, char* buf, int len) {
+    UV_CHECK_ARG(buf && len > 0, "uv_flash_attn_kernel_name: bad buffer");
+    UV_CHECK_ARG(head_dim == 128 || head_dim == 64, "uv_flash_attn_kernel_name: head_dim %d unsupported (64 or 128)", head_dim);
+    snprintf(buf, len, "%s", kAttnKernelName[attn_select(Lk, head_dim, ldk, ldvt, f16 != 0)]);
+    return 0;
+}
+
+template <bool F16>
+static int attn_entry(const char* name, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                      int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream) {
+    UV_CHECK_ARG(q && k && vt && out, "%s: null pointer", name);
+    UV_CHECK_ARG(head_dim == 128 || head_dim == 64, "%s: head_dim %d unsupported (64 or 128)", name, head_dim);
+    UV_CHECK_ARG(Lq > 0 && Lk > 0 && H > 0 && batch > 0, "%s: bad shape B=%d Lq=%d Lk=%d H=%d", name, batch, Lq, Lk, H);
+    UV_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "%s: leading dimensions must be multiples of 8 elements", name);
     UV_CHECK_ARG(ldvt >= (long)(batch - 1) * Lk + (long)((Lk + 63) / 64) * 64,
-                 "uv_flash_attn_bf16: ldvt=%ld must cover (batch-1)*Lk + Lk rounded up to 64 (batch=%d Lk=%d)", ldvt, batch, Lk);
-    UV_CHECK_ARG(batch == 1 || Lk % 8 == 0, "uv_flash_attn_bf16: batch > 1 needs Lk %% 8 == 0 (Lk=%d)", Lk);
-    UV_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0,
-                 "uv_flash_attn_bf16: pointers must be 16-byte aligned");
+                 "%s: ldvt=%ld must cover (batch-1)*Lk + Lk rounded up to 64 (batch=%d Lk=%d)", name, ldvt, batch, Lk);
+    UV_CHECK_ARG(batch == 1 || Lk % 8 == 0, "%s: batch > 1 needs Lk %% 8 == 0 (Lk=%d)", name, Lk);
+    UV_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0, "%s: pointers must be 16-byte aligned", name);
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
     a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
     a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = batch;
-    // workgroup shape: 4 waves x 2 workgroups per CU by default; UV_ATTN_WAVES=8 selects the 8-wave workgroup (A/B knob)
-    static int nw = 0;
-    if (!nw) {
-        const char* e = getenv("UV_ATTN_WAVES");
-        nw = (e && atoi(e) == 8) ? 8 : 4;
-    }
-    static int qb2 = -1;
-    if (qb2 < 0) {
-        const char* e = getenv("UV_ATTN_QB");
-        qb2 = e ? (atoi(e) == 2 ? 1 : (atoi(e) == 3 ? 2 : 0)) : 0;
-    }
+    a.scale_log2 = softmax_scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
-    unsigned long long* nostamps = nullptr;
-    a.scale_log2 = softmax_scale * 1.4426950408889634f;
-    if (qb2 && head_dim == 128) {   // 4 waves x 64 queries, one wave per SIMD
-        a.q_blocks = (Lq + 255) / 256;
-        if (qb2 == 2) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, false, 2, true>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a, nostamps);
-        else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, false, 2, false>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a, nostamps);
-        UV_CHECK_LAUNCH("uv_flash_attn_bf16");
-        return 0;
-    }
-    static int w3 = -1;
-    // A/B knob: 0 = the two-waves-per-SIMD kernel, 1 = three 4-wave workgroups per CU, 3 (default) = one 12-wave workgroup per CU
-    if (w3 < 0) { const char* e = getenv("UV_ATTN_W3"); w3 = e ? atoi(e) : 3; }
-    if (w3 && head_dim == 128 && 128 * ldvt < (1L << 30) && 64 * ldk < (1L << 30)) {   // 32-bit lane offsets of the LDS-DMA pieces
-        a.q_blocks = (Lq + 127) / 128;
-        const dim3 g3(a.q_blocks * H * batch), b3(256);
-        if (w3 == 3 && Lk >= 2048) {
-            // long key sequences: one 12-wave workgroup per CU shares each K / V^T tile among 384 queries (a third of the L2 -> LDS
-            // traffic; -2.8 % on the self-attention launches); short ones (cross-attention, Lk = 512: the prologue and the last
-            // round weigh more) keep the 4-wave workgroups (+24 % there otherwise)
-            a.q_blocks = (Lq + 383) / 384;
+    switch (attn_select(Lk, head_dim, ldk, ldvt, F16)) {
+        case ATT_FWD12:
+            a.q_blocks = attn12_blocks(Lq, H * batch);
             hipLaunchKernelGGL((flash_attn_fwd12_kernel<3, true>), dim3(a.q_blocks * H * batch), dim3(768), 0, st, a);
-        } else if (w3 == 2) hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, false>), g3, b3, 0, st, a);   // A/B: plain block order
-        else hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, true>), g3, b3, 0, st, a);
-        UV_CHECK_LAUNCH("uv_flash_attn_bf16");
-        return 0;
+            break;
+        case ATT_FWD3:
+            a.q_blocks = (Lq + 127) / 128;
+            hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, true>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a);
+            break;
+        case ATT_FWD_D128:
+            a.q_blocks = (Lq + 127) / 128;
+            hipLaunchKernelGGL((flash_attn_fwd_kernel<128, true, F16>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a);
+            break;
+        case ATT_FWD_D64:
+            a.q_blocks = (Lq + 127) / 128;
+            hipLaunchKernelGGL((flash_attn_fwd_kernel<64, false, F16>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a);
+            break;
     }
-    a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
-    const dim3 grid(a.q_blocks * H * batch), block(nw * 64);
-    static int sgb1 = -1;
-    if (sgb1 < 0) { const char* e = getenv("UV_ATTN_SGB"); sgb1 = (e && atoi(e) == 0) ? 0 : 1; }   // A/B knob, default on
-    if (head_dim == 128 && nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8>), grid, block, 0, st, a, nostamps);
-    else if (head_dim == 128 && sgb1) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, false, 1, true>), grid, block, 0, st, a, nostamps);
-    else if (head_dim == 128) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4>), grid, block, 0, st, a, nostamps);
-    else if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 8>), grid, block, 0, st, a, nostamps);
-    else hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 4>), grid, block, 0, st, a, nostamps);
-    UV_CHECK_LAUNCH("uv_flash_attn_bf16");
+    UV_CHECK_LAUNCH(name);
     return 0;
 }
 
-// Developer diagnostic (not part of include/univid_hip.h): the D=128 kernel with per-segment s_memtime stamps.
-// stamps: device buffer of q_blocks*H*nw*5 uint64 cycle sums [qk, softmax, pv, commit, barrier] per wave. Its fences
-// forbid overlaps the real kernel has: read the SHARES, never its run time.
-// The same kernel with IEEE fp16 q / k / V^T / out (fp32 softmax and accumulation): the SigLIP2 ranker's reference dtype.
-extern "C" int uv_flash_attn_f16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
-                                 void* out, long ldo, int batch, int Lq, int Lk, int H, int head_dim,
-                                 float softmax_scale, void* stream) {
-    UV_CHECK_ARG(q && k && vt && out, "uv_flash_attn_f16: null pointer");
-    UV_CHECK_ARG(head_dim == 128 || head_dim == 64, "uv_flash_attn_f16: head_dim %d unsupported (64 or 128)", head_dim);
-    UV_CHECK_ARG(Lq > 0 && Lk > 0 && H > 0 && batch > 0, "uv_flash_attn_f16: bad shape B=%d Lq=%d Lk=%d H=%d", batch, Lq, Lk, H);
-    UV_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0,
-                 "uv_flash_attn_f16: leading dimensions must be multiples of 8 elements");
-    UV_CHECK_ARG(ldvt >= (long)(batch - 1) * Lk + (long)((Lk + 63) / 64) * 64,
-                 "uv_flash_attn_f16: ldvt=%ld must cover (batch-1)*Lk + Lk rounded up to 64 (batch=%d Lk=%d)", ldvt, batch, Lk);
-    UV_CHECK_ARG(batch == 1 || Lk % 8 == 0, "uv_flash_attn_f16: batch > 1 needs Lk %% 8 == 0 (Lk=%d)", Lk);
-    UV_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0,
-                 "uv_flash_attn_f16: pointers must be 16-byte aligned");
-    AttnArgs a;
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
-    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
-    a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = batch;
-    a.scale_log2 = softmax_scale * 1.4426950408889634f;
-    a.q_blocks = (Lq + 4 * UV_ATT_QW - 1) / (4 * UV_ATT_QW);
-    const dim3 grid(a.q_blocks * H * batch), block(256);
-    unsigned long long* nostamps = nullptr;
-    if (head_dim == 128) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, false, 1, true, true>), grid, block, 0, (hipStream_t)stream, a, nostamps);
-    else hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 4, false, 1, false, true>), grid, block, 0, (hipStream_t)stream, a, nostamps);
-    UV_CHECK_LAUNCH("uv_flash_attn_f16");
-    return 0;
+extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                                  int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream) {
+    return attn_entry<false>("uv_flash_attn_bf16", q, ldq, k, ldk, vt, ldvt, out, ldo, batch, Lq, Lk, H, head_dim, softmax_scale, stream);
 }
 
-extern "C" int uvdbg_flash_attn_stamps(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out,
-                                       long ldo, int Lq, int Lk, int H, float softmax_scale, int nw,
-                                       unsigned long long* stamps, int extra_lds, void* stream) {
-    AttnArgs a;
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
-    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = 1;
-    a.q_blocks = (Lq + nw * UV_ATT_QW - 1) / (nw * UV_ATT_QW);
-    a.scale_log2 = softmax_scale * 1.4426950408889634f;
-    const dim3 grid(a.q_blocks * H), block(nw * 64);
-    // extra_lds: unused dynamic LDS, only to cap the number of co-resident workgroups per CU in occupancy experiments
-    if (extra_lds > 0) {
-        hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<128, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
-        hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<128, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
-    }
-    if (nw == 42 || nw == 43) {
-        a.q_blocks = (Lq + 255) / 256;
-        const dim3 g2(a.q_blocks * H), b2(256);
-        if (nw == 42) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true, 2, false>), g2, b2, 0, (hipStream_t)stream, a, stamps);
-        else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true, 2, true>), g2, b2, 0, (hipStream_t)stream, a, stamps);
-    } else if (nw == 44) {
-        a.q_blocks = (Lq + 127) / 128;
-        hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true, 1, true>), dim3(a.q_blocks * H), dim3(256), 0, (hipStream_t)stream, a, stamps);
-    } else if (nw == 8) hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 8, true>), grid, block, extra_lds, (hipStream_t)stream, a, stamps);
-    else hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4, true>), grid, block, extra_lds, (hipStream_t)stream, a, stamps);
-    UV_CHECK_LAUNCH("uvdbg_flash_attn_stamps");
-    return 0;
+// The same with IEEE fp16 q / k / V^T / out (fp32 softmax and accumulation): the SigLIP2 ranker's reference dtype.
+extern "C" int uv_flash_attn_f16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                                 int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream) {
+    return attn_entry<true>("uv_flash_attn_f16", q, ldq, k, ldk, vt, ldvt, out, ldo, batch, Lq, Lk, H, head_dim, softmax_scale, stream);
 }

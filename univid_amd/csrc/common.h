@@ -24,6 +24,16 @@ static inline int uv_cur_dev() {
     (void)hipGetDevice(&d);
     return (unsigned)d < UV_MAX_DEV ? d : 0;
 }
+// Compute units of the current device (256 on MI355X); launch-geometry decisions (whole rounds of workgroups) use it.
+static inline int uv_num_cus() {
+    static int cus[UV_MAX_DEV];
+    const int dev = uv_cur_dev();
+    int& n = cus[dev];
+    if (!n) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
 
 // f32 -> bf16, round-to-nearest-even (same rounding torch's .to(bfloat16) uses).
 // A plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN.

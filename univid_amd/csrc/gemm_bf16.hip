@@ -728,15 +728,7 @@ static int launch_cfg(const GemmArgs& a0, int epi, hipStream_t stream) {
     return 0;
 }
 
-static int num_cus() {
-    static int cus[UV_MAX_DEV];
-    const int dev = uv_cur_dev();
-    int& n = cus[dev];
-    if (!n) {
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    }
-    return n;
-}
+static int num_cus() { return uv_num_cus(); }
 
 template <bool F16>
 static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStream_t s);

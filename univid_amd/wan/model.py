@@ -91,9 +91,11 @@ class WanSelfAttention(nn.Module):
         self.norm_q = WanRMSNorm(dim, eps=eps)
         self.norm_k = WanRMSNorm(dim, eps=eps)
         self._prep = None
+        self._kv_cache = {}
 
     def prepare(self):
         self._prep = {n: _Prepared(getattr(self, n)) for n in ("q", "k", "v", "o")}
+        self._kv_cache = {}
 
     def _self_attn(self, h, L, grid, freqs, x_resid, gate, gate_tid, batch=1, sp=None):
         """h: bf16 [batch*L, C] modulated input (samples stacked along the token axis). Adds o(attn) * gate into x_resid
@@ -191,25 +193,48 @@ class WanCrossAttention(WanSelfAttention):
     part of UniVid's contract: Wan22ContextWrapper finds modules by `__class__.__name__ == 'WanCrossAttention'`
     and replaces `module.forward` with a closure that rescales `context` (model_pipeline.py:1745-1807)."""
 
-    def _attend(self, hq, ctx, L, Lc, batch=1):
+    def _context_kv(self, ctx, Lc, batch, kv_key):
+        """k = norm_k(Wk ctx) [batch*Lc, C] and V^T = (Wv ctx)^T of the embedded context (model.py:170-172). They depend on the
+        context and this block's weights only, not on the latent or the timestep, so across the steps of a sampling loop they are
+        computed ONCE: `kv_key` identifies the (context generation, sample group) WanModel.forward is running; None = no caching
+        (the reference-signature forward, i.e. also UniVid's text-weight hook, which rescales the context per step)."""
+        hit = self._kv_cache.get(kv_key) if kv_key is not None else None
+        if hit is not None:
+            return hit
+        C, D = self.dim, self.head_dim
+        p = self._prep
+        dev = ctx.device
+        kl = torch.empty(batch * Lc, C, dtype=BF16, device=dev)
+        if kv_key is None:
+            vt = _vt_scratch("cvt", C, batch, Lc, dev)
+        else:
+            if batch > 1 and Lc % 8:
+                raise NotImplementedError(f"stacked samples need a context length divisible by 8 (got {Lc})")
+            vt = torch.zeros(C, (batch - 1) * Lc + _round_up(Lc, 64), dtype=BF16, device=dev)
+        _lib.gemm_bf16(ctx, p["k"].w, p["k"].b, kl, EPI_BF16, M=batch * Lc)
+        _lib.gemm_bf16(ctx, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=batch * Lc)
+        _lib.rmsnorm_rope(kl, kl, self.norm_k.weight, batch * Lc, C, D, self.eps)
+        if kv_key is not None:
+            if self._kv_cache and next(iter(self._kv_cache))[0] != kv_key[0]:
+                self._kv_cache.clear()          # a new context generation: the old entries can never hit again
+            self._kv_cache[kv_key] = (kl, vt)
+        return kl, vt
+
+    def _attend(self, hq, ctx, L, Lc, batch=1, kv_key=None):
         """hq bf16 [batch*L, C] (normed queries' input), ctx bf16 [batch*Lc, C] -> attention output bf16 [batch*L, C]."""
         C, H, D = self.dim, self.num_heads, self.head_dim
         p = self._prep
         dev = hq.device
         ql = torch.empty(batch * L, C, dtype=BF16, device=dev)
-        kl = torch.empty(batch * Lc, C, dtype=BF16, device=dev)
-        vt = _vt_scratch("cvt", C, batch, Lc, dev)
         _lib.gemm_bf16(hq, p["q"].w, p["q"].b, ql, EPI_BF16, M=batch * L)
-        _lib.gemm_bf16(ctx, p["k"].w, p["k"].b, kl, EPI_BF16, M=batch * Lc)
-        _lib.gemm_bf16(ctx, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=batch * Lc)
         _lib.rmsnorm_rope(ql, ql, self.norm_q.weight, batch * L, C, D, self.eps)
-        _lib.rmsnorm_rope(kl, kl, self.norm_k.weight, batch * Lc, C, D, self.eps)
+        kl, vt = self._context_kv(ctx, Lc, batch, kv_key)
         att = torch.empty(batch * L, C, dtype=BF16, device=dev)
         _lib.flash_attn(ql, kl, vt, att, L, Lc, H, D, 1.0 / math.sqrt(D), batch=batch)
         return att
 
-    def _cross_fused(self, hq, ctx, L, Lc, x_resid, batch=1):
-        att = self._attend(hq, ctx, L, Lc, batch)
+    def _cross_fused(self, hq, ctx, L, Lc, x_resid, batch=1, kv_key=None):
+        att = self._attend(hq, ctx, L, Lc, batch, kv_key)
         p = self._prep["o"]
         _lib.gemm_bf16(att, p.w, p.b, x_resid, EPI_RESID_F32, M=batch * L)
 
@@ -248,9 +273,10 @@ class WanAttentionBlock(nn.Module):
         self.cross_attn.prepare()
         self._prep = {"ffn0": _Prepared(self.ffn[0]), "ffn2": _Prepared(self.ffn[2])}
 
-    def _run(self, x, L, e0_rows, tid, grid, freqs, ctx, first_block, batch=1, sp=None):
+    def _run(self, x, L, e0_rows, tid, grid, freqs, ctx, first_block, batch=1, sp=None, kv_key=None):
         """x: fp32 [batch*L, C] residual stream (independent samples stacked along the token axis), updated IN PLACE.
-        e0_rows: fp32 [n_t, 6C]; tid int32 [batch*L] | None; ctx: bf16 [batch*Lc, C] embedded context(s)."""
+        e0_rows: fp32 [n_t, 6C]; tid int32 [batch*L] | None; ctx: bf16 [batch*Lc, C] embedded context(s); kv_key: cache key of
+        the context's cross-attention K / V^T (WanCrossAttention._context_kv), None = recompute."""
         C = self.dim
         dev = x.device
         n_t = e0_rows.shape[0]
@@ -275,7 +301,7 @@ class WanAttentionBlock(nn.Module):
             y = y.reshape(L, C).contiguous()
             _lib.call("uv_add_bf16_resid", _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), L, C, _lib.stream_ptr())
         else:
-            self.cross_attn._cross_fused(h, ctx, Ls, Lc, x, batch)
+            self.cross_attn._cross_fused(h, ctx, Ls, Lc, x, batch, kv_key)
         # FFN (model.py:252-255)
         _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=3 * C, scale_off=4 * C, tid=tid)
         mid = torch.empty(L, self.ffn_dim, dtype=BF16, device=dev)
@@ -414,6 +440,9 @@ class WanModel(nn.Module):
             self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
                                     rope_params(1024, 2 * (d // 6))], dim=1)
         self._prep = None
+        self._ctx_cache = None   # (key, input tensors kept alive, embedded contexts, generation): see _embedded_context
+        self._ctx_gen = 0
+        self.cache_context = True   # step-constant context work (text_embedding, cross-attention K / V^T) is computed once per context
         self.sp = None   # SeqParallel when Ulysses sequence parallelism is enabled (enable_sequence_parallel)
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
 
@@ -421,10 +450,12 @@ class WanModel(nn.Module):
     def invalidate(self):
         """Forget the bf16 weight copies (call after changing parameters in place)."""
         self._prep = None
+        self._ctx_cache = None
         for b in self.blocks:
             b._prep = None
             b.self_attn._prep = None
             b.cross_attn._prep = None
+            b.cross_attn._kv_cache = {}
 
     def prepare(self):
         """Materialise the bf16 operand copies autocast would create on every call of the reference."""
@@ -484,6 +515,22 @@ class WanModel(nn.Module):
             outs.append(c)
         return torch.stack(outs)
 
+    def _embedded_context(self, context):
+        """text_embedding of the prompt embeddings, cached across forwards: in a sampling loop the same context tensors come
+        back every step (textimage2video.py:380-385), and neither text_embedding (model.py:472-478) nor the blocks'
+        cross-attention K / V projections of it (model.py:170-172) depend on the latent or the timestep. The key is the
+        identity AND version counter of every input tensor (an in-place edit bumps `_version`; the tensors are kept referenced
+        here so their storage cannot be recycled under the key); parameter changes go through invalidate().
+        Returns (embedded contexts [B, text_len, C] bf16, generation id or None when caching is off)."""
+        if not self.cache_context:
+            return self.embed_context(context), None
+        key = tuple((u.data_ptr(), u._version, tuple(u.shape), u.dtype, u.device) for u in context)
+        c = self._ctx_cache
+        if c is None or c[0] != key:
+            self._ctx_gen += 1
+            c = self._ctx_cache = (key, list(context), self.embed_context(context), self._ctx_gen)
+        return c[2], c[3]
+
     def forward(self, x, t, context, seq_len, y=None):
         r"""Same contract as the reference (model.py:410-497).
 
@@ -498,7 +545,7 @@ class WanModel(nn.Module):
             x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]
         if t.dim() == 1:  # one timestep per sample (model.py:460-461)
             t = t.view(-1, 1).expand(-1, seq_len)
-        ctx_all = self.embed_context(context)
+        ctx_all, ctx_gen = self._embedded_context(context)
         fr = _freqs_device(self.freqs, dev)
         pt, ph, pw = self.patch_size
         C = self.dim
@@ -531,6 +578,7 @@ class WanModel(nn.Module):
             tid = None if tvals.numel() == 1 else inv.to(torch.int32).contiguous()
             e_rows, e0_rows = self._time_rows(tvals.contiguous())
             ctx = ctx_all[idx[0]] if B == 1 else torch.cat([ctx_all[i] for i in idx], 0)
+            kv_key = None if ctx_gen is None else (ctx_gen, tuple(idx))
             par = self.sp if (self.sp is not None and self.sp.size > 1) else None
             if par is None:
                 n, sp_arg = L, None
@@ -546,7 +594,7 @@ class WanModel(nn.Module):
                 _lib.gemm_bf16(a, self._prep["patch"].w, self._prep["patch"].b, xs, EPI_F32_FROM_BF16)
             for li, blk in enumerate(self.blocks):
                 if par is None or n:
-                    blk._run(xs, n, e0_rows, tid, (Fp, Hp, Wp), fr, ctx, first_block=(li == 0), batch=B, sp=sp_arg)
+                    blk._run(xs, n, e0_rows, tid, (Fp, Hp, Wp), fr, ctx, first_block=(li == 0), batch=B, sp=sp_arg, kv_key=kv_key)
                 else:   # a rank without tokens still takes part in the self-attention exchanges
                     blk.self_attn._self_attn_sp(xs.new_empty(0, C).to(BF16), 0, (Fp, Hp, Wp), fr, xs, None, None, B, sp_arg)
             yh = self.head._run(xs, B * n, e_rows, tid) if B * n else xs.new_empty(0, self.head.head.out_features)

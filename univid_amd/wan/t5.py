@@ -173,15 +173,15 @@ class T5EncoderModel:
     `models_t5_umt5-xxl-enc-bf16.pth`."""
 
     def __init__(self, text_len, dtype=torch.bfloat16, device="cuda", checkpoint_path=None, tokenizer_path=None, shard_fn=None, *,
-                 tokenizer=None, model: T5Encoder = None):
+                 tokenizer=None, model: T5Encoder = None, encoder_kwargs=None):
         if dtype != torch.bfloat16:
             raise NotImplementedError("the HIP umT5 encoder is the bf16 module of the reference configuration (config.t5_dtype)")
         if shard_fn is not None:
             raise NotImplementedError("FSDP sharding of the text encoder (t5_fsdp) is not part of this build")
         self.text_len, self.dtype, self.device = text_len, dtype, torch.device(device)
         if model is None:
-            with torch.device(self.device):
-                model = umt5_xxl_encoder()
+            with torch.device(self.device):      # encoder_kwargs: T5Encoder arguments of a non-XXL checkpoint (tests)
+                model = T5Encoder(**encoder_kwargs) if encoder_kwargs else umt5_xxl_encoder()
             if checkpoint_path is not None:
                 model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"))
         self.model = model.to(device=self.device, dtype=dtype).eval().requires_grad_(False)

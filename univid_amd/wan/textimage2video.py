@@ -72,6 +72,12 @@ class TI2VConfig:
     sample_guide_scale = 5.0
     frame_num = 121
     sample_neg_prompt = ""
+    # checkpoint file names under checkpoint_dir (configs/wan_ti2v_5B.py:12-16)
+    t5_checkpoint = "models_t5_umt5-xxl-enc-bf16.pth"
+    t5_tokenizer = "google/umt5-xxl"
+    vae_checkpoint = "Wan2.2_VAE.pth"
+    vae_kwargs = {}      # extra Wan2_2_VAE constructor arguments (width-reduced test checkpoints); {} = the Wan2.2 VAE
+    t5_kwargs = None     # T5Encoder constructor arguments of a non-XXL text-encoder checkpoint; None = umT5-XXL
     dit = dict(model_type="ti2v", patch_size=(1, 2, 2), text_len=512, in_dim=48, dim=3072, ffn_dim=14336, freq_dim=256,
                text_dim=4096, out_dim=48, num_heads=24, num_layers=30, window_size=(-1, -1), qk_norm=True,
                cross_attn_norm=True, eps=1e-6)
@@ -106,6 +112,20 @@ class WanTI2V:
             from .checkpoint import load_wan_model
             model = load_wan_model(checkpoint_dir)
         self.model = model.eval().requires_grad_(False).to(self.device)
+        if checkpoint_dir is not None:
+            # textimage2video.py:88-103: the VAE and the text encoder come from the same directory. Each is loaded when its
+            # file is there and no instance was injected; a missing file leaves the stage to be injected (vae= / text_encoder=)
+            import os
+            vae_pth = os.path.join(checkpoint_dir, getattr(config, "vae_checkpoint", "Wan2.2_VAE.pth"))
+            if self.vae is None and os.path.exists(vae_pth):
+                from .vae2_2 import Wan2_2_VAE
+                self.vae = Wan2_2_VAE(vae_pth=vae_pth, device=self.device, **dict(getattr(config, "vae_kwargs", {}) or {}))
+            t5_pth = os.path.join(checkpoint_dir, getattr(config, "t5_checkpoint", "models_t5_umt5-xxl-enc-bf16.pth"))
+            t5_tok = os.path.join(checkpoint_dir, getattr(config, "t5_tokenizer", "google/umt5-xxl"))
+            if self.text_encoder is None and os.path.exists(t5_pth) and os.path.isdir(t5_tok):
+                from .t5 import T5EncoderModel
+                self.text_encoder = T5EncoderModel(text_len=config.text_len, dtype=torch.bfloat16, device=self.device, checkpoint_path=t5_pth,
+                                                   tokenizer_path=t5_tok, encoder_kwargs=getattr(config, "t5_kwargs", None))
         if use_sp:
             # textimage2video.py:106-118: Ulysses sequence parallelism over all ranks of the default process group; every rank
             # runs the same sample (same seed) and holds the full result after each forward
