@@ -107,8 +107,9 @@ def vae_metrics(device, precision, encode=True):
 
 def cpu_baseline_vae(budget_s=12.0):
     """VAE leg of the CPU baseline: the oracle's fp32 VAE decoder (oracle/wan_vae.py, bit-identical to the reference module) on
-    this host, FULL width, 720x1280, on a BOUNDED number of latent frames (the streaming decoder works one latent frame per
-    chunk: chunk 0 -> 1 frame, every later chunk -> 4 frames), extrapolated to the 13-latent-frame clip by output frames."""
+    this host, FULL width, on a BOUNDED sample: the first latent frame of a quarter-area clip (360x640; the full-size first
+    frame alone took 78 s on 256 threads), extrapolated to the 49-frame 720x1280 clip by output pixels (the convolutions'
+    FLOPs are proportional to them)."""
     from oracle import wan_vae
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
@@ -116,7 +117,7 @@ def cpu_baseline_vae(budget_s=12.0):
     vae = wan_vae.WanVAE(wan_vae.make_state_dict(cfg, 0), cfg)
     scale = wan_vae.scale_tensors()
     g = torch.Generator().manual_seed(7)
-    z = torch.randn(1, 48, 2, 45, 80, generator=g)
+    z = torch.randn(1, 48, 2, 22, 40, generator=g)
     with torch.no_grad():
         t0 = time.time()
         v = vae.decode(z[:, :, :1], scale)
@@ -126,14 +127,14 @@ def cpu_baseline_vae(budget_s=12.0):
             t0 = time.time()
             v = vae.decode(z, scale)
             secs, frames, nlat = time.time() - t0, v.shape[2], 2
-    per_frame = secs / frames
-    full = per_frame * 49
+    px = frames * v.shape[3] * v.shape[4]
+    full = secs * (49 * 720 * 1280) / px
     return {"value": round(3 * 49 * 720 * 1280 * 4 / full / 1e9, 6), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/wan_vae.WanVAE.decode (fp32, full width) of {nlat} latent frame(s) [48,{nlat},45,80] -> {frames} frame(s) "
-                      f"720x1280 in {secs:.1f} s on {cores} threads; full 49-frame clip extrapolated by output frames = {full:.0f} s"}
+            "sample": f"oracle/wan_vae.WanVAE.decode (fp32, full width) of {nlat} latent frame(s) [48,{nlat},22,40] -> {frames} frame(s) "
+                      f"{v.shape[3]}x{v.shape[4]} in {secs:.1f} s on {cores} threads; 49-frame 720x1280 clip extrapolated by output pixels = {full:.0f} s"}
 
 
-def cpu_baseline(cfg, budget_s=25.0):
+def cpu_baseline(cfg, budget_s=15.0):
     """Times the CPU restatement (oracle/, validated bit-exact against the reference modules) on this host.
 
     A full step is 300 TFLOP (hours on a CPU), so a BOUNDED sample is timed: ONE of the 30 DiT blocks at
@@ -175,7 +176,8 @@ def cpu_baseline(cfg, budget_s=25.0):
     return {"value": 1.0 / full_step_s, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle/wan_dit.block_forward: 1 of {cfg['num_layers']} DiT blocks at L={Ls} tokens "
                       f"(grid {choice}) in {ts:.1f} s on {cores} threads (bf16 autocast dtype flow), extrapolated to one "
-                      f"CFG step at L={L_TOKENS} by the SURVEY 8(d) FLOP ratio"}
+                      f"CFG step at L={L_TOKENS} by the SURVEY 8(d) FLOP ratio (the sample is ~3 % attention FLOPs, the full "
+                      f"step 32 %: the extrapolation assumes the CPU runs both at the same rate)"}
 
 
 def main():

@@ -104,6 +104,11 @@ int uv_layernorm_mod(const float* x, long ldx, void* out, long ldo, int L, int C
  * Replaces WanRMSNorm (model.py:82-85) + rope_apply (model.py:38-66) + the bf16 cast of attention.py:59-83. */
 int uv_rmsnorm_rope(const void* x, long ldx, void* out, long ldo, const float* weight, int L, int C, int head_dim,
                     float eps, const double* freqs, int F, int Hh, int Ww, int row0, void* stream);
+/* uv_rmsnorm_rope for q AND k of a self-attention in one launch (model.py:138-139, 146-147): same geometry, own norm weights;
+ * the L rows hold L / Ls stacked samples whose RoPE positions restart every Ls rows. */
+int uv_rmsnorm_rope_qk(const void* q, void* q_out, const float* q_weight, const void* k, void* k_out, const float* k_weight,
+                       long ldx, long ldo, int L, int Ls, int C, int head_dim, float eps, const double* freqs, int F, int Hh,
+                       int Ww, int row0, void* stream);
 
 /* latent [Cin,F,H,W] f32 -> im2col rows [L, Kpad] bf16, column order (c,kt,kh,kw) = Conv3d.weight.flatten(1)
  * (model.py:378-379, 448-451). */

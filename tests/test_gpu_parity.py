@@ -359,6 +359,31 @@ def test_layernorm_modulate_and_rmsnorm_rope():
         assert_bf16_kernel(out, wan_dit.rms_norm(xq, wq, 1e-6)[0].to(BF16), name=f"rmsnorm {dim}")
 
 
+def test_rmsnorm_rope_qk_single_launch_equals_per_tensor_calls():
+    """uv_rmsnorm_rope_qk (q and k of all stacked samples in one launch, RoPE positions restarting per sample) against the
+    per-tensor, per-sample uv_rmsnorm_rope calls that are checked against the oracle above: bit-identical."""
+    from univid_amd.wan.model import _freqs_device, rope_params
+    C, D, grid, B = 3072, 128, (3, 6, 8), 2
+    Ls = grid[0] * grid[1] * grid[2]
+    d = D
+    freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)), rope_params(1024, 2 * (d // 6))], dim=1)
+    fr = _freqs_device(freqs, torch.device(DEV))
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for L_rows in (Ls, 4800):                                # small (1 row per wave) and large (4 rows per wave) launch shapes
+        gr = grid if L_rows == Ls else (10, 20, 24)
+        q = torch.randn(B * L_rows, C, device=DEV, generator=g).to(BF16)
+        k = torch.randn(B * L_rows, C, device=DEV, generator=g).to(BF16)
+        wq, wk = torch.randn(C, device=DEV, generator=g), torch.randn(C, device=DEV, generator=g)
+        q1, k1 = q.clone(), k.clone()
+        for b in range(B):
+            rows = slice(b * L_rows, (b + 1) * L_rows)
+            L().rmsnorm_rope(q1[rows], q1[rows], wq, L_rows, C, D, 1e-6, fr, gr)
+            L().rmsnorm_rope(k1[rows], k1[rows], wk, L_rows, C, D, 1e-6, fr, gr)
+        q2, k2 = q.clone(), k.clone()
+        L().rmsnorm_rope_qk(q2, k2, wq, wk, B * L_rows, L_rows, C, D, 1e-6, fr, gr)
+        assert torch.equal(q1, q2) and torch.equal(k1, k2) and not torch.equal(q2, q)
+
+
 def test_unipc_and_cfg_kernels_are_bit_exact():
     """Given identical model outputs the HIP latent trajectory equals the CPU oracle's bit for bit (same host, so the
     same libm/LAPACK scalar coefficients), and the reference's golden trajectory (generated on another CPU, whose

@@ -38,3 +38,5 @@ timeit(lambda: _lib.layernorm_mod(x, h, M, C, 1e-6, mode=1, tab=tab, shift_off=0
 timeit(lambda: _lib.layernorm_mod(x, h, M, C, 1e-6, mode=2, w=w, b=b), M * C * 6, "layernorm_mod affine (norm3), 22880 rows")
 timeit(lambda: _lib.rmsnorm_rope(q[:L], q[:L], w, L, C, D, 1e-6, fr, (13, 22, 40)), L * C * 4, "rmsnorm_rope with RoPE, 11440 rows")
 timeit(lambda: _lib.rmsnorm_rope(q, q, w, M, C, D, 1e-6), M * C * 4, "rmsnorm_rope no RoPE (cross q), 22880 rows")
+k = torch.randn(B * L, C, device=dev, generator=g).to(torch.bfloat16)
+timeit(lambda: _lib.rmsnorm_rope_qk(q, k, w, b, M, L, C, D, 1e-6, fr, (13, 22, 40)), 2 * M * C * 4, "rmsnorm_rope_qk (q+k, 2 samples, RoPE), 4 x 11440 rows")

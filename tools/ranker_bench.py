@@ -37,11 +37,19 @@ class Proc:
 sc = Siglip2Scorer(device=dev, model=m, processor=Proc())
 h, f, L, nl = 768, 3072, 256, 12
 flops_frame = nl * (L * (8 * h * h + 4 * h * f) + 4 * L * L * h) + 2 * L * 768 * h + (2 * L * 2 * h * h + 4 * L * h + 2 * h * h + 4 * h * f)
-for name, fn in (("get_image_features (64 frames)", lambda: m.get_image_features(pv, mask, shapes)),
-                 ("rank_frames (text + 64 frames + top-8)", lambda: sc.rank_frames(list(range(B)), "q", 8))):
-    fn(); torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-    t = sorted(ts)[len(ts) // 2]
-    print(f"{name:42s} {t * 1e3:8.2f} ms  {B / t:9.1f} frames/s  {B * flops_frame / t / 1e12:7.1f} TFLOP/s", flush=True)
+ref = None
+for mode in ("eager", "hipGraph replay"):
+    m.vision_model.use_graph = mode != "eager"
+    for name, fn in (("get_image_features (64 frames)", lambda: m.get_image_features(pv, mask, shapes)),
+                     ("rank_frames (text + 64 frames + top-8)", lambda: sc.rank_frames(list(range(B)), "q", 8))):
+        out = fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(9):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[len(ts) // 2]
+        print(f"{mode:16s} {name:42s} {t * 1e3:8.2f} ms  {B / t:9.1f} frames/s  {B * flops_frame / t / 1e12:7.1f} TFLOP/s", flush=True)
+        if torch.is_tensor(out):
+            if ref is None:
+                ref = out.clone()
+            else:
+                print("    graph replay bit-identical to eager:", bool(torch.equal(ref, out)))

@@ -39,6 +39,7 @@ SIGNATURES = {
     "uv_interp_linear_rows_bf16": [_P, _L, _P, _L, _I, _I, _I, _P],
     "uv_l2_normalize_rows_f32": [_P, _L, _P, _L, _I, _I, _F, _P],
     "uv_rmsnorm_rope": [_P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _I, _I, _I, _I, _P],
+    "uv_rmsnorm_rope_qk": [_P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _F, _P, _I, _I, _I, _I, _P],
     "uv_patchify_bf16": [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "uv_unpatchify_f32": [_P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "uv_sinusoid_f32": [_P, _P, _I, _I, _P],
@@ -264,3 +265,13 @@ def rmsnorm_rope(x, out, weight, L, C, D, eps, freqs=None, grid=(0, 0, 0), row0=
     call("uv_rmsnorm_rope", ptr(x), x.stride(0), ptr(out), out.stride(0), ptr(weight), L, C, D, float(eps), ptr(freqs),
          int(grid[0]), int(grid[1]), int(grid[2]), int(row0), stream_ptr())
     return out
+
+
+def rmsnorm_rope_qk(q, k, q_weight, k_weight, L, Ls, C, D, eps, freqs, grid, row0=0):
+    """In-place QK RMSNorm + RoPE of q and k (same strides) in one launch; rows = L / Ls stacked samples of Ls tokens."""
+    _chk(q, torch.bfloat16, "rmsnorm_rope_qk.q")
+    _chk(k, torch.bfloat16, "rmsnorm_rope_qk.k")
+    if q.stride(0) != k.stride(0):
+        raise UnividHipError("rmsnorm_rope_qk: q and k must have the same row stride")
+    call("uv_rmsnorm_rope_qk", ptr(q), ptr(q), ptr(q_weight), ptr(k), ptr(k), ptr(k_weight), q.stride(0), q.stride(0), L, Ls, C, D,
+         float(eps), ptr(freqs), int(grid[0]), int(grid[1]), int(grid[2]), int(row0), stream_ptr())

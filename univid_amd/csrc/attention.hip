@@ -44,6 +44,7 @@ struct AttnArgs {
     bf16_t* out;       // [Lq, ldo]
     long ldq, ldk, ldvt, ldo;
     int Lq, Lk, H, q_blocks, batch;
+    int n12;           // flash_attn_fwd12_kernel: query blocks per head that own 12 units; the other q_blocks - n12 own 8
     float scale_log2;  // softmax_scale * log2(e)
 };
 
@@ -638,14 +639,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // flash_attn_fwd3_kernel (same per-wave arithmetic). Staging as in the two-waves kernel (K and V^T double-buffered, tile t+1
 // requested at the top of tile t, ONE vmcnt(0) + barrier per tile), compute body and register diet of flash_attn_fwd3_kernel
 // (32-key halves, SGPR-base DMA, immediates for the buffer parity).
-// BALANCED QUERY BLOCKS: a (sample, head) has NWU = ceil(Lq / 32) wave-units of 32 queries. Cutting it into ceil(NWU / 12) blocks
-// of 12 waves gives, at the DiT's shape (2 x 24 heads x 358 units), 1 440 workgroups = 5.6 rounds of 256 CUs: the sixth round
-// runs on 62 % of the chip. The host instead picks the block count per head (attn12_blocks) so that the workgroups fill whole
-// rounds - 32 blocks of 11 or 12 units there, 1 536 workgroups = 6 full rounds - and block j owns the units
-// [j NWU / nblk, (j+1) NWU / nblk). All 12 waves of a workgroup stage K / V^T tiles and take every barrier; waves beyond the
-// block's unit count are LOADER-ONLY (no QK / softmax / PV), which leaves their SIMD two compute waves instead of three - and a
-// wave's tile chain is latency-bound, so those run faster. Per-query arithmetic does not depend on the cut: results are
-// bit-identical for any block count.
+// QUERY BLOCKS OF 12 AND 8 UNITS: a (sample, head) has NWU = ceil(Lq / 32) wave-units of 32 queries. Cutting it into blocks of 12
+// waves only gives, at the DiT's shape (2 x 24 heads x 358 units), 1 440 workgroups = 5.6 rounds of 256 CUs: the sixth round
+// runs on 62 % of the chip for the time of a full one. A workgroup's time is set by its busiest SIMD (three waves each at 12
+// units), so what shortens the tail is workgroups with TWO waves on every SIMD: the host cuts each head into n12 blocks of 12
+// units and n8 blocks of 8 units (attn12_cut: 26 + 6 there) and orders all 12-unit blocks before all 8-unit blocks, so every CU
+// ends with short workgroups instead of some CUs ending with a long one. All 12 waves of a workgroup stage K / V^T tiles and
+// take every barrier; the waves beyond the block's unit count are LOADER-ONLY (no QK / softmax / PV). Per-query arithmetic does
+// not depend on the cut: results are bit-identical for any cut.
 // ------------------------------------------------------------------------------------------------------------------------
 template <int AHEAD = 3, bool XCD = true>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void flash_attn_fwd12_kernel(AttnArgs p) {
@@ -665,8 +666,19 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int x = vb & 7, j = vb >> 3;
         vb = x * per + min(x, rem) + j;
     }
-    const int bh = vb / p.q_blocks;
-    const int qb = vb - bh * p.q_blocks;
+    // ids [0, n12 * BH): the 12-unit blocks of all (sample, head) pairs, head-major; then the 8-unit blocks
+    const int nbh = p.H * p.batch, n8 = p.q_blocks - p.n12;
+    int bh, u0, units;
+    if (vb < p.n12 * nbh) {
+        bh = vb / p.n12;
+        u0 = (vb - bh * p.n12) * 12;
+        units = 12;
+    } else {
+        const int v2 = vb - p.n12 * nbh;
+        bh = v2 / n8;
+        u0 = p.n12 * 12 + (v2 - bh * n8) * 8;
+        units = 8;
+    }
     const int head = bh % p.H;
     {
         const long b = bh / p.H;
@@ -675,10 +687,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         p.vt += (long)b * p.Lk;
         p.out += b * p.Lq * p.ldo;
     }
-    // balanced cut: block qb of this head owns the 32-query units [u0, u1), u1 - u0 <= 12
     const int nwu = (p.Lq + UV_ATT_QW - 1) / UV_ATT_QW;
-    const int u0 = (int)((long)qb * nwu / p.q_blocks), u1 = (int)((long)(qb + 1) * nwu / p.q_blocks);
-    const bool compute_wave = wave_u < u1 - u0;
+    const bool compute_wave = wave_u < min(units, nwu - u0);      // the head's last block may be ragged
     const int q0w = (u0 + wave_u) * UV_ATT_QW;
     const long hcol = (long)head * D;
 
@@ -918,27 +928,40 @@ static AttnKernel attn_select(int Lk, int head_dim, long ldk, long ldvt, bool f1
     return Lk >= 2048 ? ATT_FWD12 : ATT_FWD3;
 }
 
-// Query blocks per (sample, head) of flash_attn_fwd12_kernel: at least ceil(NWU / 12) (a workgroup computes at most 12 units of 32
-// queries); more when that fills whole rounds of CUs. Cost model = rounds of workgroups x time of one workgroup, where a
-// workgroup with w compute waves takes t(w) = 1 + 0.095 (w - 8) for w >= 8 (measured: 12 waves per CU deliver 1.085x the
-// throughput of 8, i.e. t(12) / t(8) = 1.38) and t = 1 below (one or two waves per SIMD run the same latency-bound chain).
-// UV_ATTN12_BLOCKS (developer knob) overrides the choice, e.g. to A/B against the ceil(NWU / 12) cut.
-static int attn12_blocks(int Lq, int heads_total) {
+// Cut of a (sample, head)'s NWU = ceil(Lq / 32) query units into n12 blocks of 12 units followed by n8 blocks of 8 units for
+// flash_attn_fwd12_kernel. Model: a 12-unit workgroup takes time 1, an 8-unit one T8 = 0.725 (measured: three waves per SIMD
+// deliver 1.085x the throughput of two), CUs pick workgroups up in id order (12-unit blocks first = longest-first list
+// scheduling); the cut with the smallest simulated makespan wins, ties go to fewer workgroups.
+static void attn12_cut(int Lq, int heads_total, int* n12_out, int* n8_out) {
     const int nwu = (Lq + UV_ATT_QW - 1) / UV_ATT_QW, ncu = uv_num_cus();
-    const int nb_min = (nwu + 11) / 12;
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("UV_ATTN12_BLOCKS"); forced = e ? atoi(e) : 0; }
-    if (forced >= nb_min && forced <= nwu) return forced;
-    int best = nb_min;
-    double best_cost = 1e30;
-    for (int nb = nb_min; nb <= nwu && nb <= 2 * nb_min; ++nb) {
-        const long wgs = (long)nb * heads_total;
-        const double rounds = (double)((wgs + ncu - 1) / ncu);
-        const double w = (double)nwu / nb;
-        const double cost = rounds * (w > 8.0 ? 1.0 + 0.095 * (w - 8.0) : 1.0);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = nb; }
+    static int memo_key[2] = {0, 0}, memo_val[2] = {0, 0};
+    if (memo_key[0] == nwu && memo_key[1] == heads_total * 1024 + ncu) { *n12_out = memo_val[0]; *n8_out = memo_val[1]; return; }
+    const double T8 = 0.725;
+    int best12 = (nwu + 11) / 12, best8 = 0;
+    double best = 1e30;
+    for (int n8 = 0; n8 * 8 < nwu + 8; ++n8) {
+        const int rest = nwu - 8 * n8;
+        const int n12 = rest > 0 ? (rest + 11) / 12 : 0;
+        if (n12 == 0 && n8 * 8 - nwu >= 8) break;
+        // list scheduling on ncu identical machines: loads kept in a small array (ncu <= 1024)
+        double load[1024];
+        const int m = ncu < 1024 ? ncu : 1024;
+        for (int i = 0; i < m; ++i) load[i] = 0.0;
+        auto place = [&](long count, double t) {
+            for (long j = 0; j < count; ++j) {
+                int arg = 0;
+                for (int i = 1; i < m; ++i) if (load[i] < load[arg]) arg = i;
+                load[arg] += t;
+            }
+        };
+        place((long)n12 * heads_total, 1.0);
+        place((long)n8 * heads_total, T8);
+        double mk = 0.0;
+        for (int i = 0; i < m; ++i) mk = load[i] > mk ? load[i] : mk;
+        if (mk < best - 1e-9) { best = mk; best12 = n12; best8 = n8; }
     }
-    return best;
+    memo_key[0] = nwu; memo_key[1] = heads_total * 1024 + ncu; memo_val[0] = best12; memo_val[1] = best8;
+    *n12_out = best12; *n8_out = best8;
 }
 
 // Name of the kernel uv_flash_attn_bf16 / _f16 dispatches for this problem (bench.py labels its roofline line with it).
@@ -963,12 +986,17 @@ static int attn_entry(const char* name, const void* q, long ldq, const void* k, 
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
     a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
-    a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = batch;
+    a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = batch; a.n12 = 0;
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
     switch (attn_select(Lk, head_dim, ldk, ldvt, F16)) {
         case ATT_FWD12:
-            a.q_blocks = attn12_blocks(Lq, H * batch);
+            {
+                int n12 = 0, n8 = 0;
+                attn12_cut(Lq, H * batch, &n12, &n8);
+                a.n12 = n12;
+                a.q_blocks = n12 + n8;
+            }
             hipLaunchKernelGGL((flash_attn_fwd12_kernel<3, true>), dim3(a.q_blocks * H * batch), dim3(768), 0, st, a);
             break;
         case ATT_FWD3:

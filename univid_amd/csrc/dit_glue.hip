@@ -169,8 +169,12 @@ struct RmsRopeArgs {
     const bf16_t* x; long ldx;
     bf16_t* out; long ldo;
     const float* weight;
+    const bf16_t* x2;     // second tensor of the launch (blockIdx.y == 1): k beside q, same geometry; nullptr = none
+    bf16_t* out2;
+    const float* weight2;
     const double* freqs;  // nullptr => no rope
     int L, C, D;          // D = head_dim
+    int Ls;               // rows per sample: stacked samples restart their RoPE positions every Ls rows
     int F, Hh, Ww;        // token grid
     int nf, nh, nw;       // complex columns per axis
     int row0;             // global token index of row 0 (sequence-parallel shards), RoPE positions only
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsRopeArgs p) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     if (row0 >= p.L) return;
+    if (blockIdx.y == 1) { p.x = p.x2; p.out = p.out2; p.weight = p.weight2; }
     const int nv = p.C >> 9;                     // 8-element chunks per lane (64 lanes * 8 = 512)
     const int rem = (p.C & 511) >> 3;            // leftover chunks (C % 512 != 0, e.g. C = 256)
     const int half = p.D >> 1;
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsRopeArgs p) {
                 for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
             }
         }
-        const int grow = row + p.row0;               // token index in the whole sequence
+        const int grow = row % p.Ls + p.row0;        // token index in its sample's whole sequence
         const bool do_rope = p.freqs != nullptr && grow < p.F * p.Hh * p.Ww;
         int pf = 0, ph = 0, pw = 0;
         if (do_rope) {
@@ -276,23 +281,24 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsRopeArgs p) {
     }
 }
 
-extern "C" int uv_rmsnorm_rope(const void* x, long ldx, void* out, long ldo, const float* weight, int L, int C,
-                               int head_dim, float eps, const double* freqs, int F, int Hh, int Ww, int row0,
-                               void* stream) {
-    UV_CHECK_ARG(x && out && weight && L > 0, "uv_rmsnorm_rope: null pointer / empty");
-    UV_CHECK_ARG(C % 8 == 0 && C <= 8192, "uv_rmsnorm_rope: C=%d must be a multiple of 8 and <= 8192", C);
-    UV_CHECK_ARG(head_dim % 8 == 0 && C % head_dim == 0, "uv_rmsnorm_rope: bad head_dim %d", head_dim);
-    UV_CHECK_ARG(ldx % 8 == 0 && ldo % 8 == 0, "uv_rmsnorm_rope: ldx/ldo must be multiples of 8");
-    UV_CHECK_ARG(row0 >= 0, "uv_rmsnorm_rope: negative row offset");
+static int rmsnorm_rope_launch(const char* name, const void* x, void* out, const float* weight, const void* x2, void* out2,
+                               const float* weight2, long ldx, long ldo, int L, int Ls, int C, int head_dim, float eps,
+                               const double* freqs, int F, int Hh, int Ww, int row0, void* stream) {
+    UV_CHECK_ARG(x && out && weight && L > 0, "%s: null pointer / empty", name);
+    UV_CHECK_ARG(C % 8 == 0 && C <= 8192, "%s: C=%d must be a multiple of 8 and <= 8192", name, C);
+    UV_CHECK_ARG(head_dim % 8 == 0 && C % head_dim == 0, "%s: bad head_dim %d", name, head_dim);
+    UV_CHECK_ARG(ldx % 8 == 0 && ldo % 8 == 0, "%s: ldx/ldo must be multiples of 8", name);
+    UV_CHECK_ARG(row0 >= 0 && Ls > 0, "%s: negative row offset / bad rows per sample", name);
     if (freqs) UV_CHECK_ARG(F > 0 && Hh > 0 && Ww > 0 && F <= 1024 && Hh <= 1024 && Ww <= 1024,
-                            "uv_rmsnorm_rope: grid (%d,%d,%d) outside the 1024-row RoPE table", F, Hh, Ww);
+                            "%s: grid (%d,%d,%d) outside the 1024-row RoPE table", name, F, Hh, Ww);
     RmsRopeArgs a;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.out = (bf16_t*)out; a.ldo = ldo; a.weight = weight; a.freqs = freqs;
-    a.L = L; a.C = C; a.D = head_dim; a.F = F; a.Hh = Hh; a.Ww = Ww; a.eps = eps; a.row0 = row0;
+    a.x2 = (const bf16_t*)x2; a.out2 = (bf16_t*)out2; a.weight2 = weight2;
+    a.L = L; a.Ls = Ls; a.C = C; a.D = head_dim; a.F = F; a.Hh = Hh; a.Ww = Ww; a.eps = eps; a.row0 = row0;
     const int c = head_dim / 2;  // model.py:43  split [c - 2*(c//3), c//3, c//3]
     a.nh = c / 3; a.nw = c / 3; a.nf = c - 2 * (c / 3);
     const int rpw = L >= 4096 ? 4 : 1;
-    const dim3 grid((L + 4 * rpw - 1) / (4 * rpw)), block(256);
+    const dim3 grid((L + 4 * rpw - 1) / (4 * rpw), x2 ? 2 : 1), block(256);
     const int chunks = (C + 511) / 512;
     hipStream_t st = (hipStream_t)stream;
     if (rpw == 4) {
@@ -305,8 +311,26 @@ extern "C" int uv_rmsnorm_rope(const void* x, long ldx, void* out, long ldo, con
         else if (chunks <= 8) hipLaunchKernelGGL((rmsnorm_rope_kernel<8, 1>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((rmsnorm_rope_kernel<16, 1>), grid, block, 0, st, a);
     }
-    UV_CHECK_LAUNCH("uv_rmsnorm_rope");
+    UV_CHECK_LAUNCH(name);
     return 0;
+}
+
+extern "C" int uv_rmsnorm_rope(const void* x, long ldx, void* out, long ldo, const float* weight, int L, int C,
+                               int head_dim, float eps, const double* freqs, int F, int Hh, int Ww, int row0,
+                               void* stream) {
+    return rmsnorm_rope_launch("uv_rmsnorm_rope", x, out, weight, nullptr, nullptr, nullptr, ldx, ldo, L, L, C, head_dim, eps, freqs,
+                               F, Hh, Ww, row0, stream);
+}
+
+// q and k of a self-attention in ONE launch (same geometry, each with its own norm weight), over `L` rows holding L / Ls stacked
+// samples whose RoPE positions restart every Ls rows: 4x the rows per launch of the per-tensor, per-sample form.
+extern "C" int uv_rmsnorm_rope_qk(const void* q, void* q_out, const float* q_weight, const void* k, void* k_out,
+                                  const float* k_weight, long ldx, long ldo, int L, int Ls, int C, int head_dim, float eps,
+                                  const double* freqs, int F, int Hh, int Ww, int row0, void* stream) {
+    UV_CHECK_ARG(k && k_out && k_weight, "uv_rmsnorm_rope_qk: null pointer");
+    UV_CHECK_ARG(Ls > 0 && L % Ls == 0, "uv_rmsnorm_rope_qk: L=%d must be a whole number of samples of Ls=%d rows", L, Ls);
+    return rmsnorm_rope_launch("uv_rmsnorm_rope_qk", q, q_out, q_weight, k, k_out, k_weight, ldx, ldo, L, Ls, C, head_dim, eps,
+                               freqs, F, Hh, Ww, row0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

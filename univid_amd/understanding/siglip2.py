@@ -160,12 +160,15 @@ class Siglip2VisionModel(nn.Module):
         self.head = Siglip2PoolingHead(c)
         self._p = None
         self.op_dtype = BF16
+        self.use_graph = False     # replay each (image count, grid) group from a captured HIP graph (see _graphed_group)
+        self._graphs = {}
 
     def prepare(self, op=BF16):
         for l in self.encoder.layers:
             l.prepare(op)
         h = self.cfg["hidden_size"]
         self._op = op
+        self._graphs = {}          # graphs hold pointers into the previous operand copies
         W, B = self.head.attention.in_proj_weight, self.head.attention.in_proj_bias
         self._p = {"patch": _W(self.embeddings.patch_embedding.weight, self.embeddings.patch_embedding.bias, op),
                    "hq": _W(W[:h], B[:h], op), "hk": _W(W[h:2 * h], B[h:2 * h], op), "hv": _W(W[2 * h:], B[2 * h:], op),
@@ -195,43 +198,76 @@ class Siglip2VisionModel(nn.Module):
                 raise ValueError("pixel_attention_mask does not mark exactly the first h*w patches of an image")
             ii = torch.tensor(idx, device=dev)
             px = pixel_values.to(dev)[ii, :n].reshape(G * n, -1).float().contiguous()
-            Kp = p["patch"].w.shape[1]
-            a = torch.zeros(G * n, Kp, dtype=BF16, device=dev)
-            a[:, :px.shape[1]] = px.to(BF16)
-            x = self.embeddings.positions(hw).to(dev).repeat(G, 1).contiguous()       # residual stream starts as the positions
-            _lib.gemm_bf16(a, p["patch"].w, p["patch"].b, x, EPI_RESID_F32)            # + patch embedding
-            for l in self.encoder.layers:
-                l.run(x, G, n, n)
-            y = torch.empty(G * n, h, dtype=BF16, device=dev)
-            _lib.layernorm_mod(x, y, G * n, h, self.post_layernorm.eps, mode=2, w=self.post_layernorm.weight, b=self.post_layernorm.bias)
-            # attention pooling: one probe query per image over its n tokens (nn.MultiheadAttention with packed in_proj)
-            q1 = torch.empty(1, h, dtype=BF16, device=dev)
-            _lib.gemm_bf16(p["probe"], p["hq"].w, p["hq"].b, q1, EPI_BF16)
-            q = q1.expand(G, h).contiguous()
-            att = torch.empty(G, h, dtype=BF16, device=dev)
-            if G == 1 or n % 8 == 0:
-                k = torch.empty(G * n, h, dtype=BF16, device=dev)
-                vt = torch.zeros(h, (G - 1) * n + _round_up(n, 64), dtype=BF16, device=dev)
-                _lib.gemm_bf16(y, p["hk"].w, p["hk"].b, k, EPI_BF16)
-                _lib.gemm_bf16(y, p["hv"].w, p["hv"].b, vt, EPI_BF16_T)
-                _lib.flash_attn(q, k, vt, att, 1, n, H, D, D ** -0.5, batch=G)
+            if self.use_graph:
+                out[ii] = self._graphed_group(px, hw, G)
             else:
-                for g in range(G):
-                    yb = y[g * n:(g + 1) * n]
-                    k = torch.empty(n, h, dtype=BF16, device=dev)
-                    vt = torch.zeros(h, _round_up(n, 64), dtype=BF16, device=dev)
-                    _lib.gemm_bf16(yb, p["hk"].w, p["hk"].b, k, EPI_BF16)
-                    _lib.gemm_bf16(yb, p["hv"].w, p["hv"].b, vt, EPI_BF16_T)
-                    _lib.flash_attn(q[g:g + 1], k, vt, att[g:g + 1], 1, n, H, D, D ** -0.5)
-            z = torch.empty(G, h, dtype=torch.float32, device=dev)
-            _lib.gemm_bf16(att, p["ho"].w, p["ho"].b, z, EPI_F32_FROM_BF16)
-            zn = torch.empty(G, h, dtype=BF16, device=dev)
-            _lib.layernorm_mod(z, zn, G, h, self.head.layernorm.eps, mode=2, w=self.head.layernorm.weight, b=self.head.layernorm.bias)
-            mid = torch.empty(G, p["hfc1"].w.shape[0], dtype=BF16, device=dev)
-            _lib.gemm_bf16(zn, p["hfc1"].w, p["hfc1"].b, mid, EPI_GELU_BF16)
-            _lib.gemm_bf16(mid, p["hfc2"].w, p["hfc2"].b, z, EPI_RESID_F32)
-            out[ii] = z
+                out[ii] = self._pooled_group(px, hw, G)
         return out
+
+    def _graphed_group(self, px, hw, G):
+        """One captured HIP graph per (image count, grid): the ~150 launches of a 12-layer tower take ~3-4 us of host time each,
+        about as long as the kernels themselves at 64 frames x 256 patches; replaying them as one graph removes the gaps.
+        Static input / output buffers; the kernels and their order are those of the eager path (bit-identical)."""
+        key = (G, hw, px.shape[1], self._op)
+        ent = self._graphs.get(key)
+        if ent is None:
+            buf = torch.empty_like(px)
+            buf.copy_(px)
+            self._pooled_group(buf, hw, G)                      # eager warm-up: scratch, function attributes
+            torch.cuda.synchronize(px.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                z = self._pooled_group(buf, hw, G)
+            ent = self._graphs[key] = (g, buf, z)
+        g, buf, z = ent
+        buf.copy_(px)
+        g.replay()
+        return z.clone()
+
+    def _pooled_group(self, px, hw, G):
+        """px fp32 [G*n, 3*p*p]: the patches of G images with the same (h, w) grid -> pooler_output [G, h] fp32."""
+        dev = px.device
+        c, p = self.cfg, self._p
+        BF16 = self._op
+        h, H = c["hidden_size"], c["num_attention_heads"]
+        D = h // H
+        n = hw[0] * hw[1]
+        Kp = p["patch"].w.shape[1]
+        a = torch.zeros(G * n, Kp, dtype=BF16, device=dev)
+        a[:, :px.shape[1]] = px.to(BF16)
+        x = self.embeddings.positions(hw).to(dev).repeat(G, 1).contiguous()       # residual stream starts as the positions
+        _lib.gemm_bf16(a, p["patch"].w, p["patch"].b, x, EPI_RESID_F32)            # + patch embedding
+        for l in self.encoder.layers:
+            l.run(x, G, n, n)
+        y = torch.empty(G * n, h, dtype=BF16, device=dev)
+        _lib.layernorm_mod(x, y, G * n, h, self.post_layernorm.eps, mode=2, w=self.post_layernorm.weight, b=self.post_layernorm.bias)
+        # attention pooling: one probe query per image over its n tokens (nn.MultiheadAttention with packed in_proj)
+        q1 = torch.empty(1, h, dtype=BF16, device=dev)
+        _lib.gemm_bf16(p["probe"], p["hq"].w, p["hq"].b, q1, EPI_BF16)
+        q = q1.expand(G, h).contiguous()
+        att = torch.empty(G, h, dtype=BF16, device=dev)
+        if G == 1 or n % 8 == 0:
+            k = torch.empty(G * n, h, dtype=BF16, device=dev)
+            vt = torch.zeros(h, (G - 1) * n + _round_up(n, 64), dtype=BF16, device=dev)
+            _lib.gemm_bf16(y, p["hk"].w, p["hk"].b, k, EPI_BF16)
+            _lib.gemm_bf16(y, p["hv"].w, p["hv"].b, vt, EPI_BF16_T)
+            _lib.flash_attn(q, k, vt, att, 1, n, H, D, D ** -0.5, batch=G)
+        else:
+            for g in range(G):
+                yb = y[g * n:(g + 1) * n]
+                k = torch.empty(n, h, dtype=BF16, device=dev)
+                vt = torch.zeros(h, _round_up(n, 64), dtype=BF16, device=dev)
+                _lib.gemm_bf16(yb, p["hk"].w, p["hk"].b, k, EPI_BF16)
+                _lib.gemm_bf16(yb, p["hv"].w, p["hv"].b, vt, EPI_BF16_T)
+                _lib.flash_attn(q[g:g + 1], k, vt, att[g:g + 1], 1, n, H, D, D ** -0.5)
+        z = torch.empty(G, h, dtype=torch.float32, device=dev)
+        _lib.gemm_bf16(att, p["ho"].w, p["ho"].b, z, EPI_F32_FROM_BF16)
+        zn = torch.empty(G, h, dtype=BF16, device=dev)
+        _lib.layernorm_mod(z, zn, G, h, self.head.layernorm.eps, mode=2, w=self.head.layernorm.weight, b=self.head.layernorm.bias)
+        mid = torch.empty(G, p["hfc1"].w.shape[0], dtype=BF16, device=dev)
+        _lib.gemm_bf16(zn, p["hfc1"].w, p["hfc1"].b, mid, EPI_GELU_BF16)
+        _lib.gemm_bf16(mid, p["hfc2"].w, p["hfc2"].b, z, EPI_RESID_F32)
+        return z
 
 
 class Siglip2TextEmbeddings(nn.Module):

@@ -112,10 +112,8 @@ class WanSelfAttention(nn.Module):
         _lib.gemm_bf16(h, p["q"].w, p["q"].b, ql, EPI_BF16, M=M)
         _lib.gemm_bf16(h, p["k"].w, p["k"].b, kl, EPI_BF16, M=M)
         _lib.gemm_bf16(h, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=M)   # V^T [C, tokens]: sample b = columns b*L..
-        for b in range(batch):   # RoPE positions restart with every sample
-            rows = slice(b * L, (b + 1) * L)
-            _lib.rmsnorm_rope(ql[rows], ql[rows], self.norm_q.weight, L, C, D, self.eps, freqs, grid)
-            _lib.rmsnorm_rope(kl[rows], kl[rows], self.norm_k.weight, L, C, D, self.eps, freqs, grid)
+        # q and k of every stacked sample in one launch (RoPE positions restart with every sample)
+        _lib.rmsnorm_rope_qk(ql, kl, self.norm_q.weight, self.norm_k.weight, M, L, C, D, self.eps, freqs, grid)
         att = torch.empty(M, C, dtype=BF16, device=dev)
         _lib.flash_attn(ql, kl, vt, att, L, L, H, D, 1.0 / math.sqrt(D), batch=batch)
         _lib.gemm_bf16(att, p["o"].w, p["o"].b, x_resid, EPI_GATE_RESID_F32, M=M, gate=gate, gate_tid=gate_tid)
@@ -531,11 +529,17 @@ class WanModel(nn.Module):
             c = self._ctx_cache = (key, list(context), self.embed_context(context), self._ctx_gen)
         return c[2], c[3]
 
-    def forward(self, x, t, context, seq_len, y=None):
+    def forward(self, x, t, context, seq_len, y=None, *, t_rows=None):
         r"""Same contract as the reference (model.py:410-497).
 
         x: List[Tensor[C_in, F, H, W]] fp32; t: Tensor[B] or Tensor[B, seq_len]; context: List[Tensor[L<=text_len,
         text_dim]]; seq_len: int. Returns List[Tensor[C_out, F, H, W]] float32.
+
+        t_rows (extension, keyword-only): the caller's own table of the DISTINCT timesteps instead of `t`:
+        `(tvals fp32 [n_t] on the device, sorted ascending, tid int32 [B*L] token -> row | None when n_t == 1)`. With it the
+        forward contains no device -> host round trip (finding the distinct values of a [B, seq_len] tensor needs one), which
+        is what makes it capturable in a HIP graph (WanTI2V.denoise builds the table from the sampler's scalar timestep and
+        the i2v mask). Only for equal-shape samples (one stacked group).
         """
         if self.model_type == "i2v":
             assert y is not None
@@ -543,7 +547,7 @@ class WanModel(nn.Module):
         dev = self.patch_embedding.weight.device
         if y is not None:
             x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]
-        if t.dim() == 1:  # one timestep per sample (model.py:460-461)
+        if t_rows is None and t.dim() == 1:  # one timestep per sample (model.py:460-461)
             t = t.view(-1, 1).expand(-1, seq_len)
         ctx_all, ctx_gen = self._embedded_context(context)
         fr = _freqs_device(self.freqs, dev)
@@ -573,9 +577,16 @@ class WanModel(nn.Module):
             for j, i in enumerate(idx):
                 _lib.call("uv_patchify_bf16", _lib.ptr(xs_in[i]), _lib.ptr(a[j * L:]), a.stride(0), cin, F, H, W, pt, ph, pw, Kp, sp())
             # timesteps: distinct values -> rows; token -> row map (padding tokens beyond L are never computed)
-            tb = torch.cat([t[i].to(device=dev, dtype=torch.float32).flatten()[:L] for i in idx])
-            tvals, inv = torch.unique(tb, return_inverse=True)
-            tid = None if tvals.numel() == 1 else inv.to(torch.int32).contiguous()
+            if t_rows is not None:
+                if len(groups) != 1:
+                    raise ValueError("t_rows= needs samples of one shape (a single stacked group)")
+                tvals, tid = t_rows
+                if tid is not None and tid.numel() != B * L:
+                    raise ValueError(f"t_rows: tid must hold {B * L} token -> row indices, got {tid.numel()}")
+            else:
+                tb = torch.cat([t[i].to(device=dev, dtype=torch.float32).flatten()[:L] for i in idx])
+                tvals, inv = torch.unique(tb, return_inverse=True)          # device -> host sync (sizes the table)
+                tid = None if tvals.numel() == 1 else inv.to(torch.int32).contiguous()
             e_rows, e0_rows = self._time_rows(tvals.contiguous())
             ctx = ctx_all[idx[0]] if B == 1 else torch.cat([ctx_all[i] for i in idx], 0)
             kv_key = None if ctx_gen is None else (ctx_gen, tuple(idx))

@@ -83,6 +83,49 @@ class TI2VConfig:
                cross_attn_norm=True, eps=1e-6)
 
 
+class _GraphedPair:
+    """The cond + uncond DiT forward of one denoise step as ONE captured HIP graph, replayed every step.
+
+    What changes from step to step is data, not structure: the latent (copied into a static buffer) and the timestep (written
+    into the static table of distinct timesteps - one row for t2v, {0, t} for i2v whose first-frame tokens sit at timestep 0,
+    textimage2video.py:573 - which `WanModel.forward(..., t_rows=)` takes instead of the per-token tensor). The context work
+    (text_embedding, cross-attention K / V^T) is served from WanModel's context cache, filled by the eager warm-up forward
+    before the capture. Every kernel is the one the eager path launches, in the same order: outputs are bit-identical.
+    """
+    def __init__(self, model, latent, context, context_null, seq_len, i2v_mask, key=None):
+        dev = latent.device
+        self.key = key
+        L = seq_len
+        self.model = model
+        self.lat = torch.empty_like(latent)
+        n_t = 1 if i2v_mask is None else 2
+        self.tvals = torch.zeros(n_t, dtype=torch.float32, device=dev)
+        if i2v_mask is None:
+            tid = None
+        else:   # mask 0 (first latent frame) -> row 0 (timestep 0), mask 1 -> row 1 (timestep t); padding tokens never exist here
+            one = i2v_mask.to(torch.int32)
+            tid = torch.cat([one, one]).contiguous()
+        ctx = [context[0], context_null[0]]
+        self.lat.copy_(latent)
+        with torch.no_grad():
+            # eager warm-up on the capture inputs: weight preparation, context cache, scratch buffers, function attributes
+            model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid))
+            torch.cuda.synchronize(dev)
+            # the graph reads the cached context tensors by address: keep them alive for as long as the graph lives, and remember
+            # which context generation they belong to (a later generation means the model has dropped them from its cache)
+            self.gen = model._ctx_gen
+            self.keep = (model._ctx_cache, [dict(b.cross_attn._kv_cache) for b in model.blocks], ctx)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid))
+
+    def __call__(self, latent, t):
+        self.lat.copy_(latent)
+        self.tvals[-1:].fill_(t)             # the value travels as a kernel argument (no host buffer to race with); row 0 stays 0 for i2v
+        self.graph.replay()
+        return self.out[0], self.out[1]      # static outputs: consumed by the sampler update before the next replay
+
+
 class WanTI2V:
     def __init__(self, config=TI2VConfig, checkpoint_dir=None, device_id=0, rank=0, t5_fsdp=False, dit_fsdp=False,
                  use_sp=False, t5_cpu=False, init_on_cpu=True, convert_model_dtype=False, *, model: WanModel = None,
@@ -103,6 +146,7 @@ class WanTI2V:
         self.patch_size = config.patch_size
         self.sp_size = 1
         self.cfgp = None
+        self._runner = None      # cached _GraphedPair (HIP graph of the CFG pair's forward) of the last graph-mode denoise
         self.sample_neg_prompt = config.sample_neg_prompt
         self.text_encoder = text_encoder
         self.vae = vae
@@ -161,11 +205,16 @@ class WanTI2V:
                         n_prompt=n_prompt, seed=seed, offload_model=offload_model, **kw)
 
     # ---- the hot loop ----------------------------------------------------------------------------------------
-    def denoise(self, noise, context, context_null, sampling_steps, shift, guide_scale, z=None, record=None):
+    def denoise(self, noise, context, context_null, sampling_steps, shift, guide_scale, z=None, record=None, graph=None):
         """Steps of t2v (:356-394) / i2v (:548-601) on a given noise latent [C, f, h, w] (fp32, on device).
 
         z: first-frame latent [C, 1, h, w] switches on the i2v masking (mask2 zero on frame 0, :550-551, :598).
         record: optional list receiving (noise_pred, latent) per step (costs one extra latent write per step).
+        graph: replay the CFG pair's DiT forward from a captured HIP graph (one capture per latent shape, all steps replay it;
+            the sampler update stays eager because its coefficients are host scalars that change every step). None = automatic:
+            on for small latents, where ~100 launches of a few microseconds each make the step launch-bound; off for large ones
+            (kernel time is 99 % of a step at 49 x 704 x 1280) and whenever a hook or a parallel mode owns the forward.
+            Results are bit-identical either way (same kernels, same order).
         Returns the final latent.
         """
         dev = self.device
@@ -182,7 +231,37 @@ class WanTI2V:
         c, f, h, w = latent.shape
         seq_len = math.ceil((h * w) / (self.patch_size[1] * self.patch_size[2]) * f / self.sp_size) * self.sp_size
         base_mask = mask2[0][0][:, ::2, ::2].flatten()
+        plain = (self.cfgp is None and self.sp_size == 1 and "forward" not in self.model.__dict__ and
+                 not any("forward" in b.cross_attn.__dict__ for b in self.model.blocks))
+        n_tok = base_mask.numel()
+        if graph is None:
+            graph = plain and n_tok <= 2048 and n_tok % 8 == 0
+        elif graph and not plain:
+            raise NotImplementedError("graph=True needs the plain single-process forward (no text-weight hook, CFG pair or SP mode)")
+        runner = None
+        if graph:
+            # one captured graph per (latent shape, mode, contexts, prepared weights): generations that repeat them replay it
+            key = (tuple(latent.shape), i2v, tuple((u.data_ptr(), u._version) for u in list(context) + list(context_null)),
+                   id(self.model._prep))
+            runner = self._runner if (self._runner is not None and self._runner.key == key and
+                                      self._runner.gen == self.model._ctx_gen) else None
+            if runner is None:
+                self._runner = None      # frees the old graph's pool before the new capture
+                runner = self._runner = _GraphedPair(self.model, latent, context, context_null, seq_len, base_mask if i2v else None, key)
         for t in timesteps:
+            if runner is not None:
+                cond, uncond = runner(latent, float(t))
+                res = sched.step_cfg(cond.unsqueeze(0), uncond.unsqueeze(0), guide_scale, t, latent.unsqueeze(0),
+                                     want_noise_pred=record is not None)
+                if record is not None:
+                    latent, npred = res[0].squeeze(0), res[1].squeeze(0)
+                else:
+                    latent = res.squeeze(0)
+                if i2v:
+                    latent = ((1.0 - mask2[0]) * z + mask2[0] * latent).contiguous()
+                if record is not None:
+                    record.append((npred, latent.clone()))
+                continue
             ts = torch.stack([t]).to(dev)
             temp_ts = base_mask * ts                                                   # :373
             temp_ts = torch.cat([temp_ts, temp_ts.new_ones(seq_len - temp_ts.size(0)) * ts])
