@@ -337,6 +337,91 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
 }
 
 
+// The fp32 read-modify-write epilogues of the 256x256 ping-pong kernel, ROW-COALESCED through LDS. In the MFMA's own layout a
+// lane holds 4 consecutive columns of one row and a 16x16 fragment spans 16 rows x 64 B: every x load / store instruction of
+// the fragment-wise epilogue touches 16 different 12-KB-strided rows with 64 B each. Here the workgroup's (now idle) staging
+// LDS takes the bf16-rounded product y as fp32 [128 rows][256 cols] (one half of the tile at a time, 128 KiB, 16-byte chunks
+// XOR-swizzled by row & 7 so that neither the fragment-shaped writes nor the row-shaped reads conflict), and then each wave
+// walks whole rows: one ds_read_b128, one 1-KiB-contiguous x load, one 1-KiB-contiguous store per row - the access shape HBM and
+// the address path like best. Arithmetic per element is unchanged: x + float(bf16(acc + bias)) [* gate], so the result is
+// bit-identical to the fragment-wise epilogue.
+template <int EPI, bool F16>
+__device__ __forceinline__ void epi_rmw_rows_lds(const GemmArgs& p, char* smem, const f32x4 (&acc)[2][2][2][4], int m0, int n0,
+                                                 int wave, int lane) {
+    static_assert(EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32, "rmw epilogues only");
+    constexpr bool GATE = EPI == UV_EPI_GATE_RESID_F32;
+    constexpr int D = 8;                       // rows in flight per wave
+    const int wr = wave >> 2, wc = wave & 3;
+    const int frow = lane & 15, fq = lane >> 4;
+    // bias of this lane's 4 columns in each of its 4 column fragments (hn, i)
+    float bv[2][2][4];
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = min(n0 + hn * 128 + wc * 32 + i * 16 + 4 * fq, p.N - 4);
+            const u32x2 bb = p.bias ? *(const u32x2*)(p.bias + n) : (u32x2){0u, 0u};
+            bv[hn][i][0] = in16<F16>((bf16_t)(bb[0] & 0xffff));
+            bv[hn][i][1] = in16<F16>((bf16_t)(bb[0] >> 16));
+            bv[hn][i][2] = in16<F16>((bf16_t)(bb[1] & 0xffff));
+            bv[hn][i][3] = in16<F16>((bf16_t)(bb[1] >> 16));
+        }
+    const int n = n0 + 4 * lane;               // this lane's 4 columns in the row phase
+    const bool n_ok = n < p.N;
+    const int nc = min(n, p.N - 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // ---- y of rows 128 h .. 128 h + 127 -> LDS (fragment-shaped writes)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = wr * 64 + j * 16 + frow;
+                    const int chunk = hn * 32 + wc * 8 + i * 4 + fq;
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = round16<F16>(acc[hn][h][i][j][e] + bv[hn][i][e]);
+                    *(f32x4*)(smem + row * 1024 + ((chunk ^ (row & 7)) << 4)) = y;
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- rows 16 wave .. 16 wave + 15 of the half: x (+)= y (* gate), D rows in flight
+        const int mbase = m0 + h * 128 + wave * 16;
+        f32x4 xb[D], gb[D];
+        // token -> gate row of this wave's 16 rows: ONE load (lane r holds row r's index), broadcast per row by readlane, so
+        // the gate loads below do not sit behind a dependent index load each
+        int tid16 = 0;
+        if (GATE && p.gate_tid) tid16 = p.gate_tid[min(mbase + (lane & 15), p.M - 1)];
+        auto issue = [&](int rr, int slot) {
+            const int m = min(mbase + rr, p.M - 1);
+            xb[slot] = *(const f32x4*)((const float*)p.out + (long)m * p.ldo + nc);
+            if (GATE) {
+                const int t = __builtin_amdgcn_readlane(tid16, rr);
+                gb[slot] = *(const f32x4*)(p.gate + (long)t * p.gate_stride + nc);
+            }
+        };
+#pragma unroll
+        for (int rr = 0; rr < D; ++rr) issue(rr, rr);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int slot = rr % D;
+            const int row = wave * 16 + rr;
+            const f32x4 y = *(const f32x4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
+            f32x4 x = xb[slot];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = GATE ? __fadd_rn(x[e], __fmul_rn(y[e], gb[slot][e])) : __fadd_rn(x[e], y[e]);
+            if (mbase + rr < p.M && n_ok) *(f32x4*)((float*)p.out + (long)(mbase + rr) * p.ldo + n) = x;
+            if (rr + D < 16) issue(rr + D, slot);
+        }
+        if (h == 0) {   // the second half overwrites the staging area: every wave must have read its rows
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 256x256x64 tile, 8 waves in two groups that run half a phase apart ("ping-pong"): while one group issues its 16 MFMAs
 // of a phase, the other group (the second wave of every SIMD) reads its fragments from LDS and issues the LDS-DMA of a
@@ -576,9 +661,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(0); UV_TS(tE[1]) UV_SB();                                          \
     tE_prev = tE[1]; tB_prev = tB[1];
 #define UV_KTILE(T, B, O, ST1, ST2)                                                               \
-    if constexpr (VAR == 6) { UV_KTILE6(T, B, O, ST1, ST2) } else if constexpr (VAR == 5) { UV_KTILE5(T, B, O, ST1, ST2) } else if constexpr (VAR >= 2) { UV_KTILE2(T, B, O, ST1, ST2) } else { UV_KTILE0(T, B, O, ST1, ST2) }
+    if constexpr (VAR == 6) { UV_KTILE6(T, B, O, ST1, ST2) } else if constexpr (VAR == 5 || VAR == 7) { UV_KTILE5(T, B, O, ST1, ST2) } else if constexpr (VAR >= 2) { UV_KTILE2(T, B, O, ST1, ST2) } else { UV_KTILE0(T, B, O, ST1, ST2) }
 
-    if constexpr (VAR == 5 || VAR == 6) {
+    if constexpr (VAR == 5 || VAR == 6 || VAR == 7) {
         // prologue: W0 W1 A0 A1 of K tile 0, W0 W1 A0 of K tile 1; vmcnt(8) = W0 W1 A0 of K tile 0 landed
         UV_STAGE(w_src[0], 0, 2 * HALF) UV_STAGE(w_src[1], 0, 3 * HALF) UV_STAGE(a_src[0], 0, 0) UV_STAGE(a_src[1], 0, HALF)
         UV_STAGE(w_src[0], 1, BUF + 2 * HALF) UV_STAGE(w_src[1], 1, BUF + 3 * HALF) UV_STAGE(a_src[0], 1, BUF)
@@ -617,7 +702,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     }
     const unsigned long long r_loop_end = VAR >= 2 ? __builtin_amdgcn_s_memrealtime() : 0;
 
-    if constexpr (EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) {
+    if constexpr ((EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) && VAR != 0 && VAR != 7) {
+        // every wave has left the K loop's last LDS reads behind (the loop ends on a barrier both groups take)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        epi_rmw_rows_lds<EPI, F16>(p, smem, acc, m0, n0, wave, lane);
+    } else if constexpr (EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) {
+        // VAR 0 / 7 (tile_cfg 14 / 15, A/B references): the fragment-wise read-modify-write epilogue
         int mb[32], nb[32];
         f32x4 av[32];
 #pragma unroll
@@ -783,6 +874,7 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
     }
     if (tile_cfg == 8) return launch_m_split<F16>(a, epilogue, 7, s);
     if (tile_cfg == 9) return launch_m_split<F16>(a, epilogue, 5, s);
+    if (tile_cfg == 16) return launch_m_split<F16>(a, epilogue, 15, s);
     return launch_by_cfg<F16>(a, epilogue, tile_cfg, s);
 }
 
@@ -835,7 +927,8 @@ static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStrea
         case 7:
             UV_CHECK_ARG(K % 128 == 0 && K >= 256, "uv_gemm_bf16_nt: tile_cfg 7 needs K %% 128 == 0 and K >= 256 (K=%d)", K);
             return launch_8ph<5, F16>(a, epilogue, s);
-        case 14: if constexpr (!F16) return launch_8ph<0>(a, epilogue, s); else break;   // the 4-phase-per-K-tile schedule (A/B reference)
+        case 14: if constexpr (!F16) return launch_8ph<0>(a, epilogue, s); else break;
+        case 15: if constexpr (!F16) return launch_8ph<7>(a, epilogue, s); else break;   // A/B reference: the default schedule with the fragment-wise RMW epilogue   // the 4-phase-per-K-tile schedule (A/B reference)
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown tile_cfg %d", tile_cfg);
             return -1;
