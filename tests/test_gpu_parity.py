@@ -186,22 +186,45 @@ def test_gemm_bf16_pingpong_ring_split(M, N, K, cfgs):
         assert (outT[:, M:] == 0).all()
 
 
-@pytest.mark.parametrize("M,N,K", [(22880, 3072, 3072), (2300, 2048, 640)])
+@pytest.mark.parametrize("M,N,K", [(22880, 3072, 3072), (2300, 2048, 640), (22880, 3072, 14336)])
 def test_gemm_schedules_bit_identical(M, N, K):
-    """Race screen at full size: the default ping-pong schedule (7), the 4-phase reference schedule (14), the leftover-row
-    split (8) and the 16-wave kernel (5) accumulate in the same K order, so their FULL outputs must agree bit for bit; an LDS
-    hazard (fragment read before its DMA landed, half-tile restaged too early) would show as a mismatching tile."""
-    from univid_amd._lib import EPI_BF16
+    """Race screen at full size: the persistent ping-pong kernel (17 / 18 = with the ragged rows split off; what the automatic
+    choice 0 takes for large projections), the one-tile-per-workgroup ping-pong schedule (7), the 4-phase reference schedule
+    (14), the leftover-row split (8) and the 16-wave kernel (5) accumulate in the same K order, so their FULL outputs must
+    agree bit for bit; an LDS hazard (fragment read before its DMA landed, half-tile restaged too early, a next-tile prefetch
+    landing in a buffer still being read) would show as a mismatching tile. Also the fp32 read-modify-write epilogue staged
+    through LDS against the fragment-wise one (15 / 16)."""
+    from univid_amd._lib import EPI_BF16, EPI_BF16_T, EPI_GATE_RESID_F32, EPI_GELU_BF16
     g = torch.Generator(device=DEV).manual_seed(3)
     a = (torch.rand(M, K, device=DEV, generator=g) * 2 - 1).to(BF16)
     w = ((torch.rand(N, K, device=DEV, generator=g) * 2 - 1) * 0.05).to(BF16)
+    bias = (torch.rand(N, device=DEV, generator=g) - 0.5).to(BF16)
+    big = M >= 4096
     ref = torch.zeros(M, N, device=DEV, dtype=BF16)
     L().gemm_bf16(a, w, None, ref, EPI_BF16, tile_cfg=5)
     for rep in range(3):
-        for cfg in (7, 14, 8, 0):
+        for cfg in (7, 14, 8, 0) + ((18,) if big else ()):
             out = torch.zeros(M, N, device=DEV, dtype=BF16)
             L().gemm_bf16(a, w, None, out, EPI_BF16, tile_cfg=cfg)
             assert torch.equal(out, ref), f"cfg {cfg} rep {rep}: {int((out != ref).sum())} elements differ"
+    if not big:
+        return
+    # the other epilogues of the persistent kernel against the one-tile-per-workgroup launch (8) / the fragment-wise RMW epilogue (16)
+    for epi in (EPI_GELU_BF16, EPI_BF16_T):
+        shape = (N, (M + 63) // 64 * 64) if epi == EPI_BF16_T else (M, N)
+        r, o = torch.zeros(shape, device=DEV, dtype=BF16), torch.zeros(shape, device=DEV, dtype=BF16)
+        L().gemm_bf16(a, w, bias, r, epi, tile_cfg=8)
+        L().gemm_bf16(a, w, bias, o, epi, tile_cfg=0)
+        assert torch.equal(o, r), f"epilogue {epi}: persistent != one tile per workgroup"
+    x0 = torch.rand(M, N, device=DEV, generator=g)
+    gate = torch.rand(2, N, device=DEV, generator=g)
+    tid = (torch.arange(M, device=DEV) * 2 // M).to(torch.int32)
+    outs = []
+    for cfg in (16, 8, 0):
+        x = x0.clone()
+        L().gemm_bf16(a, w, bias, x, EPI_GATE_RESID_F32, gate=gate, gate_tid=tid, tile_cfg=cfg)
+        outs.append(x)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "row-coalesced RMW epilogue != fragment-wise"
 
 
 def test_gemm_rejects_bad_shapes():
@@ -357,6 +380,66 @@ def test_layernorm_modulate_and_rmsnorm_rope():
         assert_bf16_kernel(out, ref.view(Lr + 3, dim).to(BF16), name=f"rmsnorm+rope {dim}")
         L().rmsnorm_rope(xq[0].to(DEV), out, wq.to(DEV), Lr + 3, dim, dim // heads, 1e-6)
         assert_bf16_kernel(out, wan_dit.rms_norm(xq, wq, 1e-6)[0].to(BF16), name=f"rmsnorm {dim}")
+
+
+def test_full_size_glue_kernels_sampled_rows_vs_oracle():
+    """VALUE checks at BASELINE's full size (cond + uncond stacked: 2 x 11 440 tokens x 3072): the row-wise kernels run on the
+    whole tensors, and a sample of rows - first / last rows of each sample, tile and wave boundaries, random ones - is compared
+    with the CPU oracle's functions on those rows: LayerNorm + AdaLN modulation, affine LayerNorm, QK RMSNorm + 3-axis RoPE
+    through the fused q/k launch (positions restart per sample), and the gated fp32 residual epilogue of the persistent GEMM."""
+    from oracle import wan_dit
+    from univid_amd._lib import EPI_GATE_RESID_F32
+    from univid_amd.wan.model import _freqs_device
+    Ls, B, C, H = 11440, 2, 3072, 24
+    grid = (13, 22, 40)
+    M = B * Ls
+    g = torch.Generator(device=DEV).manual_seed(17)
+    rows = torch.unique(torch.cat([torch.tensor([0, 1, 3, 4, 255, 256, 879, 880, Ls - 1, Ls, Ls + 1, Ls + 879, Ls + 880, M - 2, M - 1]),
+                                   torch.randint(0, M, (48,))]))
+    x = torch.randn(M, C, device=DEV, generator=g) * 2 + 0.3
+    tab = torch.randn(2, 6 * C, device=DEV, generator=g) * 0.3
+    tid = (torch.arange(M, device=DEV) % Ls >= 880).to(torch.int32)          # i2v-like: first latent frame on its own row
+    h = torch.empty(M, C, dtype=BF16, device=DEV)
+    L().layernorm_mod(x, h, M, C, 1e-6, mode=1, tab=tab, shift_off=3 * C, scale_off=4 * C, tid=tid)
+    xr, tr, tabc = x[rows].cpu(), tid[rows].long().cpu(), tab.cpu()
+    ref = (wan_dit.layer_norm(xr, 1e-6).float() * (1 + tabc[tr, 4 * C:5 * C]) + tabc[tr, 3 * C:4 * C]).to(BF16)
+    assert_bf16_kernel(h[rows], ref, name="full-size ln+modulate")
+    w, b = torch.randn(C, device=DEV, generator=g) * 0.1 + 1, torch.randn(C, device=DEV, generator=g) * 0.1
+    L().layernorm_mod(x, h, M, C, 1e-6, mode=2, w=w, b=b)
+    assert_bf16_kernel(h[rows], wan_dit.layer_norm(xr, 1e-6, w.cpu(), b.cpu()).to(BF16), name="full-size ln affine")
+    # QK RMSNorm + RoPE, q and k of both samples in one launch
+    q = (torch.randn(M, C, device=DEV, generator=g) * 1.5).to(BF16)
+    k = (torch.randn(M, C, device=DEV, generator=g) * 1.5).to(BF16)
+    wq, wk = torch.randn(C, device=DEV, generator=g) * 0.1 + 1, torch.randn(C, device=DEV, generator=g) * 0.1 + 1
+    q_in, k_in = q[rows].cpu(), k[rows].cpu()
+    freqs = wan_dit.rope_table(C // H)
+    L().rmsnorm_rope_qk(q, k, wq, wk, M, Ls, C, C // H, 1e-6, _freqs_device(freqs, torch.device(DEV)), grid)
+    pos = (rows % Ls).tolist()
+    for got, xin, wt, nm in ((q[rows], q_in, wq.cpu(), "q"), (k[rows], k_in, wk.cpu(), "k")):
+        y = wan_dit.rms_norm(xin.unsqueeze(0), wt, 1e-6).view(len(pos), H, C // H)         # [rows, H, D] fp32
+        # rope_apply on single-token "sequences" placed at their (f, h, w) position: rotate each sampled row with its own factors
+        c = C // H // 2
+        fa, fb, fc = freqs.split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
+        out_rows = []
+        for i, pidx in enumerate(pos):
+            f_, rem = divmod(pidx, grid[1] * grid[2])
+            h_, w_ = divmod(rem, grid[2])
+            fi = torch.cat([fa[f_], fb[h_], fc[w_]]).view(1, -1)
+            xi = torch.view_as_complex(y[i].to(torch.float64).reshape(H, -1, 2))
+            out_rows.append(torch.view_as_real(xi * fi).flatten(1).float())
+        ref = torch.stack(out_rows).reshape(len(pos), C).to(BF16)
+        assert_bf16_kernel(got, ref, name=f"full-size rmsnorm+rope {nm}")
+    # gated fp32 residual epilogue (x + bf16(acc + bias) * gate[tid]) of the o-projection shape
+    a = (torch.rand(M, C, device=DEV, generator=g) * 2 - 1).to(BF16)
+    wo = ((torch.rand(C, C, device=DEV, generator=g) * 2 - 1) * 0.05).to(BF16)
+    bias = (torch.rand(C, device=DEV, generator=g) - 0.5).to(BF16)
+    x0 = x[rows].cpu().double()
+    L().gemm_bf16(a, wo, bias, x, EPI_GATE_RESID_F32, gate=tab[:, 2 * C:3 * C], gate_tid=tid)
+    acc = a[rows].cpu().double() @ wo.cpu().double().t() + bias.cpu().double()
+    want = x0 + acc.to(BF16).double() * tabc[tr, 2 * C:3 * C].double()
+    d = (x[rows].cpu().double() - want).abs()
+    tol = (bf16_ulp(acc.float()).double() + 2e-5 * acc.abs().max()) * tabc[tr, 2 * C:3 * C].abs().double() + 1e-6
+    assert (d <= tol).all() and (d <= 1e-6).float().mean() > 0.999, f"max err {float(d.max()):.3e}"
 
 
 def test_rmsnorm_rope_qk_single_launch_equals_per_tensor_calls():

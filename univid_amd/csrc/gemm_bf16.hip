@@ -23,6 +23,7 @@
 //   uv_gemm_bf16_nt       shape-based choice, leftover-row split (launch_m_split)
 //   uvdbg_gemm_stamps     diagnostic build with in-kernel cycle stamps (tools/gemm_stamps.py), not part of the ABI
 #include "common.h"
+#include <stdlib.h>
 
 #define UV_BK 64  // k elements per LDS tile (128-byte rows)
 
@@ -568,10 +569,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
 //     phase B   LDS reads A[1] (8)              MFMA (A1,W1) (A1,W0)   DMA W[0] W[1] A[0] of K tile t+2
 // Every half-tile is restaged one phase after its only read phase, so the reads are retired (lgkmcnt(0)) BEFORE the first
 // barrier; each phase waits vmcnt(8) after its own DMA issue, which retires the half-tiles read in the NEXT phase.
-#define UV_KTILE5(T, B, O, ST1, ST2)                                                              \
+// UV_KTILE5X names the K-tile indices of its two staging groups separately (K1: the A[1] half staged in phase A, K2: W[0] W[1]
+// A[0] staged in phase B): the persistent kernel stages the NEXT output tile's first K tiles through the same code at a tile's end.
+#define UV_KTILE5(T, B, O, ST1, ST2) UV_KTILE5X((T) + 1, (T) + 2, B, O, ST1, ST2)
+#define UV_KTILE5X(K1, K2, B, O, ST1, ST2)                                                        \
     UV_RD_W(B, 0, w0) UV_RD_W(B, 1, w1) UV_RD_A(B, 0)                                             \
     if (ST1) {                                                                                    \
-        UV_STAGE(a_src[1], (T) + 1, (O) * BUF + HALF)                                             \
+        UV_STAGE(a_src[1], K1, (O) * BUF + HALF)                                                  \
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
     } else {                                                                                      \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
@@ -582,9 +586,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(0); UV_SCHED(); UV_SB();                                           \
     UV_RD_A(B, 1)                                                                                 \
     if (ST2) {                                                                                    \
-        UV_STAGE(w_src[0], (T) + 2, (B) * BUF + 2 * HALF)                                         \
-        UV_STAGE(w_src[1], (T) + 2, (B) * BUF + 3 * HALF)                                         \
-        UV_STAGE(a_src[0], (T) + 2, (B) * BUF)                                                    \
+        UV_STAGE(w_src[0], K2, (B) * BUF + 2 * HALF)                                              \
+        UV_STAGE(w_src[1], K2, (B) * BUF + 3 * HALF)                                              \
+        UV_STAGE(a_src[0], K2, (B) * BUF)                                                         \
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
     } else if (ST1) {                                                                             \
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                          \
@@ -747,6 +751,160 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the ping-pong kernel (the default for the large projections): one workgroup per CU walks a list of
+// 256x256 output tiles instead of one workgroup per tile. In the one-tile-per-workgroup launch a CU pays, per tile, the
+// dispatch of the next workgroup (3.7 us between a workgroup's end and its successor's entry, in-kernel stamps) and the
+// pipeline fill (2.0 us until the first K tile has landed) on top of 70 us of K loop and 5.4 us of epilogue. Here
+//   * the tile list of a workgroup is fixed by its id: XCD x (workgroups b with b % 8 == x) owns the same contiguous range of
+//     logical tiles as in the dynamic launch and its G = gridDim / 8 workgroups take them round-robin, so the tiles in flight
+//     on an XCD at any time are G consecutive ones of the 4-tall column walk - the L2 footprint is unchanged;
+//   * the last two K tiles of an output tile stage the FIRST two K tiles of the next one through the same schedule (the
+//     source pointers move to the next tile exactly where the schedule stops needing the old ones), so the next K loop starts
+//     with its operands landed: no fill, no prologue. The read-modify-write epilogues stage y through the same LDS and
+//     therefore restart with a prologue instead (they still save the dispatch).
+// Per-tile arithmetic (K order, MFMA order, epilogue) is the one of gemm_bf16_8ph_kernel<EPI, 5>: results are bit-identical.
+// Needs M % 256 == 0 and N % 256 == 0 (no clamped rows: the host splits ragged rows off to the small-tile kernel), an even
+// K / 64 >= 4 and gridDim % 8 == 0.
+// (Tried and dropped: waiting for the prefetched K tiles ahead of the epilogue and skipping the first K tile's waits, so that the
+// epilogue's stores drain behind the next K loop - as a peeled first K tile or as a run-time predicate on the waits it costs
+// 40-60 spilled registers in hipcc's allocation of this kernel and 10-50 % of its speed.)
+template <int EPI, bool F16 = false>
+__global__ __launch_bounds__(512) void gemm_bf16_8ph_persist_kernel(GemmArgs p) {
+    constexpr bool TRANS = (EPI == UV_EPI_BF16_T);
+    constexpr bool RMW = (EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32);
+    constexpr int VAR = 5;           // the macros below are shared with gemm_bf16_8ph_kernel
+    constexpr int HALF = 16384;
+    constexpr int BUF = 4 * HALF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- this workgroup's tile list
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x >> 3;
+    int first, cnt;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        cnt = q + (xcd < r ? 1 : 0);
+    }
+    int cur = blockIdx.x >> 3;
+    if (cur >= cnt) return;
+    constexpr int GM = 4;
+    const int group_sz = GM * p.tiles_n;
+    auto origin = [&](int bid, int& m0, int& n0) {
+        const int group = bid / group_sz;
+        const int first_m = group * GM;
+        const int gm = min(GM, p.tiles_m - first_m);
+        const int in_group = bid - group * group_sz;
+        m0 = (first_m + in_group % gm) * 256;
+        n0 = (in_group / gm) * 256;
+    };
+    int m0, n0;
+    origin(first + cur, m0, n0);
+
+    const int srow = lane >> 3, pchunk = lane & 7;
+    const bf16_t* a_src[2][2];
+    const bf16_t* w_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 8 + wave) * 8 + srow;
+            const int c = pchunk ^ ((row >> 1) & 7);
+            a_src[h][i] = p.A + (long)(m0 + h * 128 + row) * p.lda + c * 8;
+            w_src[h][i] = p.W + (long)(n0 + h * 128 + row) * p.ldw + c * 8;
+        }
+    char* const my_dst = smem + wave * 1024;
+    const int nk = p.K / UV_BK;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int lx = (fq ^ (frow >> 1)) << 4;
+    const char* const la = smem + (wr * 64 + frow) * 128;
+    const char* const lw = smem + 2 * HALF + (wc * 32 + frow) * 128;
+    f32x4 acc[2][2][2][4];
+    bf16x8 af[4][2], w0[2][2], w1[2][2];
+
+    auto move_ptrs = [&](const bf16_t* (&src)[2], long d) { src[0] += d; src[1] += d; };
+    bool fresh = true;               // the next K loop needs the prologue (first tile; every tile of the LDS-staged epilogues)
+    for (;;) {
+        if (fresh) {
+            // prologue: W0 W1 A0 A1 of K tile 0, W0 W1 A0 of K tile 1; vmcnt(8) = W0 W1 A0 of K tile 0 landed
+            UV_STAGE(w_src[0], 0, 2 * HALF) UV_STAGE(w_src[1], 0, 3 * HALF) UV_STAGE(a_src[0], 0, 0) UV_STAGE(a_src[1], 0, HALF)
+            UV_STAGE(w_src[0], 1, BUF + 2 * HALF) UV_STAGE(w_src[1], 1, BUF + 3 * HALF) UV_STAGE(a_src[0], 1, BUF)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            UV_SB();
+        }
+        fresh = RMW;
+        if (wr == 1) UV_SB();        // the second group runs one barrier behind the first
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        const int nxt = cur + G;
+        const bool has_next = nxt < cnt;
+        int m1 = m0, n1 = n0;
+        long dA = 0, dW = 0;         // element offsets from this tile's operand panels to the next tile's (0: the last tile)
+        if (has_next) {
+            origin(first + nxt, m1, n1);
+            dA = (long)(m1 - m0) * p.lda;
+            dW = (long)(n1 - n0) * p.ldw;
+        }
+        int t = 0;
+        for (; t + 2 < nk; t += 2) {
+            UV_KTILE5(t, 0, 1, true, true)
+            UV_KTILE5(t + 1, 1, 0, true, true)
+        }
+        if constexpr (!RMW) {
+            // K tiles nk-2 and nk-1 of this output tile, ONE code path for every tile (a second copy of the MFMA schedule behind
+            // a branch makes hipcc shuttle all 128 accumulators through copies and spill): staged meanwhile are A[1] of K tile
+            // nk-1 (old pointer) and then K tiles 0 and 1 of the next output tile. The workgroup's last tile "prefetches" its own
+            // first K tiles again (dA = dW = 0: 128 KiB of harmless loads, drained before the workgroup ends).
+            move_ptrs(w_src[0], dW); move_ptrs(w_src[1], dW); move_ptrs(a_src[0], dA);
+            UV_KTILE5X(nk - 1, 0, 0, 1, true, true)
+            move_ptrs(a_src[1], dA);
+            UV_KTILE5X(0, 1, 1, 0, true, true)
+        } else {
+            UV_KTILE5(t, 0, 1, true, false)
+            UV_KTILE5(t + 1, 1, 0, false, false)
+            move_ptrs(w_src[0], dW); move_ptrs(w_src[1], dW); move_ptrs(a_src[0], dA); move_ptrs(a_src[1], dA);
+        }
+        if (wr == 0) UV_SB();        // both groups have left the K loop
+
+        if constexpr (RMW) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            epi_rmw_rows_lds<EPI, F16>(p, smem, acc, m0, n0, wave, lane);
+            if (has_next) {          // the next prologue overwrites the staging area: every wave must have read its rows
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            epi_frag<EPI, F16>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], frow, fq);
+        }
+        if (!has_next) break;
+        m0 = m1; n0 = n1; cur = nxt;
+    }
+    // the last tile's self-prefetch (and every store) must have landed before the workgroup's LDS is handed on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int VAR = 0, bool F16 = false>
 static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
     GemmArgs a = a0;
@@ -779,6 +937,47 @@ static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
             return -1;
     }
 #undef UV_LAUNCH8
+    UV_CHECK_LAUNCH("uv_gemm_bf16_nt");
+    return 0;
+}
+
+template <bool F16 = false>
+static int launch_8ph_persist(const GemmArgs& a0, int epi, hipStream_t stream) {
+    GemmArgs a = a0;
+    UV_CHECK_ARG(a.M % 256 == 0 && a.N % 256 == 0, "uv_gemm_bf16_nt: the persistent kernel needs whole 256x256 tiles (M=%d N=%d)", a.M, a.N);
+    a.tiles_m = a.M / 256;
+    a.tiles_n = a.N / 256;
+    const int tiles = a.tiles_m * a.tiles_n;
+    int wgs = uv_num_cus() & ~7;
+    if (wgs > tiles) wgs = tiles & ~7;
+    UV_CHECK_ARG(wgs >= 8, "uv_gemm_bf16_nt: too few tiles (%d) for the persistent kernel", tiles);
+    const dim3 grid(wgs), block(512);
+    const size_t lds = 128 * 1024;
+#define UV_LAUNCH8P(E)                                                                             \
+    case E: {                                                                                      \
+        auto kern = gemm_bf16_8ph_persist_kernel<E, F16>;                                          \
+        static bool attr_set[UV_MAX_DEV];                                                          \
+        bool& attr_done = attr_set[uv_cur_dev()];                                                  \
+        if (!attr_done) {                                                                          \
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                (int)lds);                                                         \
+            attr_done = true;                                                                      \
+        }                                                                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                     \
+        break;                                                                                     \
+    }
+    switch (epi) {
+        UV_LAUNCH8P(UV_EPI_BF16)
+        UV_LAUNCH8P(UV_EPI_GELU_BF16)
+        UV_LAUNCH8P(UV_EPI_F32_FROM_BF16)
+        UV_LAUNCH8P(UV_EPI_RESID_F32)
+        UV_LAUNCH8P(UV_EPI_GATE_RESID_F32)
+        UV_LAUNCH8P(UV_EPI_BF16_T)
+        default:
+            uv_set_error("uv_gemm_bf16_nt: unknown epilogue %d", epi);
+            return -1;
+    }
+#undef UV_LAUNCH8P
     UV_CHECK_LAUNCH("uv_gemm_bf16_nt");
     return 0;
 }
@@ -826,12 +1025,16 @@ static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStrea
 
 // Rows that fill whole rounds of 256x256 tiles go to the big-tile kernel; the leftover rows (which would otherwise cost a
 // whole extra round on a fraction of the CUs) run as 128x128 tiles. Same arithmetic per element either way.
+// m_main > 0 names the split point explicitly (a multiple of 256).
 template <bool F16>
-static int launch_m_split(const GemmArgs& a, int epilogue, int main_cfg, hipStream_t s) {
+static int launch_m_split(const GemmArgs& a, int epilogue, int main_cfg, hipStream_t s, long m_main = 0) {
     const long tiles_n = (a.N + 255) / 256, tiles_m = (a.M + 255) / 256;
-    const long rounds = tiles_m * tiles_n / num_cus();
-    const long m_main = rounds * num_cus() / tiles_n * 256;
-    if (rounds == 0 || m_main <= 0 || m_main >= a.M) return launch_by_cfg<F16>(a, epilogue, main_cfg, s);
+    if (m_main <= 0) {
+        const long rounds = tiles_m * tiles_n / num_cus();
+        m_main = rounds * num_cus() / tiles_n * 256;
+        if (rounds == 0) m_main = 0;
+    }
+    if (m_main <= 0 || m_main >= a.M) return launch_by_cfg<F16>(a, epilogue, main_cfg, s);
     GemmArgs am = a, at = a;
     am.M = (int)m_main;
     at.M = a.M - (int)m_main;
@@ -863,18 +1066,27 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
     a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.gate_stride = gate_stride;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0; a.dbg = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (tile_cfg == 0 && M >= 2048 && N >= 1024 && N % 256 == 0 && K % 128 == 0 && K >= 256) {
-        // Large projections: 256x256 tiles, one workgroup per CU, on the 8-wave ping-pong kernel. When the tile count is
-        // just above a whole number of rounds, the leftover rows are split off so they do not cost a full extra round.
-        const int main_cfg = 7;
-        const long tiles = (long)((M + 255) / 256) * (N / 256);
+    if (tile_cfg == 0 && M >= 2048 && N >= 1024 && N % 256 == 0 && K % 128 == 0 && K >= 384) {
+        // Large projections: 256x256 tiles on the PERSISTENT 8-wave ping-pong kernel (one workgroup per CU walking its tile
+        // list). It takes whole tiles only; rows beyond the last multiple of 256 - and, when the tile count is just above a
+        // whole number of rounds, the rows of that partial round - run as 128x128 tiles on the small-tile kernel.
+        const long tn = N / 256, tm_full = M / 256;
+        const long tiles = (long)((M + 255) / 256) * tn;
         const long rounds = tiles / num_cus(), rest = tiles - rounds * num_cus();
-        if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) return launch_m_split<F16>(a, epilogue, main_cfg, s);
-        return launch_by_cfg<F16>(a, epilogue, main_cfg, s);
+        long m_main = tm_full * 256;
+        if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) m_main = rounds * num_cus() / tn * 256;
+        static int persist = -1;                       // developer A/B knob: UV_GEMM_PERSIST=0 keeps one tile per workgroup
+        if (persist < 0) { const char* e = getenv("UV_GEMM_PERSIST"); persist = (e && atoi(e) == 0) ? 0 : 1; }
+        if (!persist || m_main / 256 * tn < 2L * num_cus()) {      // under two rounds of work: the one-tile-per-workgroup launch
+            if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) return launch_m_split<F16>(a, epilogue, 7, s);
+            return launch_by_cfg<F16>(a, epilogue, 7, s);
+        }
+        return launch_m_split<F16>(a, epilogue, 17, s, m_main);
     }
     if (tile_cfg == 8) return launch_m_split<F16>(a, epilogue, 7, s);
     if (tile_cfg == 9) return launch_m_split<F16>(a, epilogue, 5, s);
     if (tile_cfg == 16) return launch_m_split<F16>(a, epilogue, 15, s);
+    if (tile_cfg == 18) return launch_m_split<F16>(a, epilogue, 17, s, (long)(M / 256) * 256 < M ? (long)(M / 256) * 256 : 0);
     return launch_by_cfg<F16>(a, epilogue, tile_cfg, s);
 }
 
@@ -928,7 +1140,10 @@ static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStrea
             UV_CHECK_ARG(K % 128 == 0 && K >= 256, "uv_gemm_bf16_nt: tile_cfg 7 needs K %% 128 == 0 and K >= 256 (K=%d)", K);
             return launch_8ph<5, F16>(a, epilogue, s);
         case 14: if constexpr (!F16) return launch_8ph<0>(a, epilogue, s); else break;
-        case 15: if constexpr (!F16) return launch_8ph<7>(a, epilogue, s); else break;   // A/B reference: the default schedule with the fragment-wise RMW epilogue   // the 4-phase-per-K-tile schedule (A/B reference)
+        case 15: if constexpr (!F16) return launch_8ph<7>(a, epilogue, s); else break;
+        case 17:
+            UV_CHECK_ARG(K % 128 == 0 && K >= 384, "uv_gemm_bf16_nt: tile_cfg 17 needs K %% 128 == 0 and K >= 384 (K=%d)", K);
+            return launch_8ph_persist<F16>(a, epilogue, s);   // A/B reference: the default schedule with the fragment-wise RMW epilogue   // the 4-phase-per-K-tile schedule (A/B reference)
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown tile_cfg %d", tile_cfg);
             return -1;
