@@ -213,6 +213,9 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    if os.environ.get("UV_BENCH_DRYRUN"):      # launcher plumbing check (tests/test_host_logic.py): no GPU is touched
+        print(json.dumps({"dryrun": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus}), flush=True)
+        return
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: start one rank per GPU "
                          f"(`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`)")

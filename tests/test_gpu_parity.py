@@ -819,8 +819,9 @@ def test_dit_block_ti2v5b_width_1014_tokens_vs_oracle():
 
 
 def SAMPLER10_GATE(what):
-    # 10 steps take 5x larger steps than 50: measured (profiles/r02_parity_margins.json) x 1.5
-    return 5e-3 if what.startswith("noise_pred") else 3e-3
+    # 10 steps take 5x larger steps than 50. Measured on MI355X (profiles/r02_parity_margins.json): noise_pred 1.9e-3 (step 0) ->
+    # 3.3e-3 (step 9), latents 1.4e-5 -> 5.2e-4. Gates = 1.5 x the largest measured value.
+    return 5e-3 if what.startswith("noise_pred") else 8e-4
 
 
 def test_sampler_trajectories_vs_golden():

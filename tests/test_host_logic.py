@@ -285,3 +285,25 @@ def test_calls_refuse_host_or_mixed_device_pointers():
     p.dev, q.dev = 0, 1
     with pytest.raises(_lib.UnividHipError, match="ONE GPU"):
         _lib.call("uv_cast_f32_bf16", p, q, 32, _lib.stream_ptr())
+
+
+def test_bench_bare_multi_gpu_invocation_starts_one_rank_per_gpu():
+    """`python bench.py --gpus N` without a launcher: the parent (which never touches the GPU) starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` as a CHILD and relays its output; under the
+    launcher, WORLD_SIZE must equal --gpus. Dry run: the ranks print their environment and exit before any GPU call."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, UV_BENCH_DRYRUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(l["rank"] for l in lines) == [0, 1] and all(l["world"] == 2 and l["gpus"] == 2 for l in lines), r.stdout
+    # a launcher world that disagrees with --gpus is an error, not a silent run
+    env2 = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
+    env2.pop("UV_BENCH_DRYRUN", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in (r.stderr + r.stdout)
