@@ -69,5 +69,37 @@ if __name__ == "__main__":
         stats(sys.argv[2])
     elif sys.argv[1] == "stats_all":
         stats(sys.argv[2], whole=True)
-    else:
+    elif sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3])
+
+
+def clocks(path):
+    """rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES per dispatch -> per-kernel effective
+    clock (GRBM_GUI_ACTIVE / 8 XCDs / duration, MI355X_MICROARCH.md 'DVFS give-back') and matrix-pipe occupancy
+    (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM cycles per XCD))."""
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = {}
+    for r in csv.DictReader(open(path)):
+        k = (r["Kernel_Name"], r["Grid_Size"], r["Dispatch_Id"])
+        per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[k] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    agg = collections.defaultdict(list)
+    for (name, grid, _), c in per.items():
+        if "at::native" in name or "rocclr" in name or "rocprim" in name or dur[(name, grid, _)] < 20000:
+            continue
+        gui = sum(c.get("GRBM_GUI_ACTIVE", [0]))
+        mfma = sum(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [0]))
+        ns = dur[(name, grid, _)]
+        clk = gui / 8 / ns                       # GHz: cycles per XCD / ns
+        busy = mfma / (gui / 8 * 256 * 4) if gui else 0.0
+        agg[(name, grid)].append((ns, clk, busy))
+    print("| kernel | grid | dispatches | avg us | effective clock GHz | matrix pipe busy | busy x clock / 2.4 GHz |")
+    print("|---|---|---|---|---|---|---|")
+    for (name, grid), v in sorted(agg.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
+        n = len(v)
+        us, clk, busy = sum(x[0] for x in v) / n / 1e3, sum(x[1] for x in v) / n, sum(x[2] for x in v) / n
+        print(f"| `{short(name)}` | {grid} | {n} | {us:.1f} | {clk:.2f} | {100 * busy:.1f} % | {busy * clk / 2.4:.3f} |")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "clocks":
+    clocks(sys.argv[2])
