@@ -1210,6 +1210,14 @@ def test_conv3d_kernel_geometries():
     ref = F.conv3d(x, w4, b4, stride=(2, 1, 1))                                            # downsample3d time_conv
     got = run(cl(x), w4, b4, 2, 6, 7, st=2)
     assert_f32_close(got.permute(3, 0, 1, 2), ref[0], rtol=1e-4, atol=1e-4, name="time stride 2")
+    # column-tile choices of the exact-f32 kernel: 256 x 16 tiles for Cout <= 16 (the decoder's 256 -> 12 head convolution),
+    # 160-wide tiles for the encoder's 160 / 320-channel stages, 128-wide otherwise (ragged last column tile at Cout = 96 above)
+    xl = torch.randn(1, 64, 3, 19, 23, generator=g)                                        # 1311 pixels: ragged row tiles too
+    for co in (12, 160, 320, 256):
+        wc, bc = torch.randn(co, 64, 3, 3, 3, generator=g) * 0.05, torch.randn(co, generator=g)
+        ref = F.conv3d(F.pad(xl, (1, 1, 1, 1, 2, 0)), wc, bc)
+        got = run(cl(F.pad(xl, (0, 0, 0, 0, 2, 0))), wc, bc, 3, 19, 23, ph=1, pw=1)
+        assert_f32_close(got.permute(3, 0, 1, 2), ref[0], rtol=1e-4, atol=1e-4, name=f"3x3x3, Cout {co}")
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-    constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
+    constexpr int A_INSTR = BM / 8 / NW, W_INSTR = (BN / 8 + NW - 1) / NW;   // a narrow W tile (BN = 16) is staged by the first waves only
+    static_assert(BM % (8 * NW) == 0, "A tile rows must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
         const int koff = (KT) * 32;                                                                                   \
         _Pragma("unroll") for (int i = 0; i < W_INSTR; ++i) {                                                         \
             const float* wsrc = w_src[i] + koff;                                                                      \
-            __builtin_amdgcn_global_load_lds(wsrc, (lds_void_c*)(sbase + A_BYTES + (i * NW + wave) * 1024), 16, 0, 0);\
+            if ((BN / 8) % NW == 0 || (i * NW + wave) * 8 < BN)                                                       \
+                __builtin_amdgcn_global_load_lds(wsrc, (lds_void_c*)(sbase + A_BYTES + (i * NW + wave) * 1024), 16, 0, 0);\
         }                                                                                                             \
         s_ci += 32;                                                                                                   \
         if (s_ci >= p.Cin) {                                                                                          \
@@ -268,7 +270,14 @@ static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, c
     const long t256 = (long)((a.M + 255) / 256) * ((Cout + 255) / 256);
     const long t128 = (long)((a.M + 255) / 256) * ((Cout + 127) / 128);
     if (prec == 0) {
-        launch_conv<128, 128, 2, 2, 0>(a, s);
+        // exact f32: 128-wide column tiles, except where they would mostly compute padding:
+        //   Cout a multiple of 160 but not of 128 (the encoder's 160 / 320 channel stages): 160-wide tiles, no padded columns
+        //     (128-wide ones compute 256 columns for 160: 37.5 % of the MFMA work wasted; 384 for 320: 17 %);
+        //   Cout <= 16 (the decoder's last convolution, 256 -> 12 channels on full-resolution frames): 256 x 16 tiles
+        //     (a 128-wide tile computes 128 columns for 12).
+        if (Cout <= 16) launch_conv<256, 16, 4, 1, 0>(a, s);
+        else if (Cout % 160 == 0 && Cout % 128 != 0) launch_conv<128, 160, 2, 2, 0>(a, s);
+        else launch_conv<128, 128, 2, 2, 0>(a, s);
     } else if (prec == 1) {
         if (Cout >= 256 && t256 >= 256) launch_conv<256, 256, 4, 4, 1>(a, s);
         else if (t128 >= 256) launch_conv<256, 128, 4, 2, 1>(a, s);
