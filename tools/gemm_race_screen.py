@@ -1,5 +1,5 @@
-"""Race screen for the ping-pong GEMM schedules: the default schedule (tile_cfg 7) against the 4-phase reference schedule
-(tile_cfg 14) and the 16-wave kernel (tile_cfg 5), FULL output, bit for bit (all three accumulate in the same K order),
+"""Race screen for the ping-pong GEMM schedules: the persistent kernel (tile_cfg 0 / 18), the one-tile-per-workgroup schedule
+(tile_cfg 7 / 8) against the 4-phase reference schedule (tile_cfg 14) and the 16-wave kernel (tile_cfg 5), FULL output, bit for bit (all three accumulate in the same K order),
 repeated while the chip is busy. Any LDS hazard (a fragment read before its DMA landed, a half-tile restaged too early)
 shows up as a mismatching tile."""
 import os, sys, torch
@@ -16,7 +16,7 @@ for (M, N, K) in [(22880, 3072, 3072), (22880, 14336, 3072), (22880, 3072, 14336
     ref = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
     _lib.gemm_bf16(A, W, None, ref, EPI_BF16, tile_cfg=5)
     for rep in range(int(os.environ.get("REPS", 6))):
-        for cfg in (7, 14, 8):
+        for cfg in (7, 14, 8, 0) + ((18,) if M >= 8192 else ()):
             out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
             _lib.gemm_bf16(A, W, None, out, EPI_BF16, tile_cfg=cfg)
             if not torch.equal(out, ref):

@@ -21,7 +21,6 @@
 //   gemm_bf16_nt_kernel   generic BM x BN tile, NS LDS stages: 128x128 / 8 waves / 4-stage ring for leftover-row strips
 //                         and small-M projections (tile_cfg 12), 2-stage 4-wave and 16-wave forms for everything else
 //   uv_gemm_bf16_nt       shape-based choice, leftover-row split (launch_m_split)
-//   uvdbg_gemm_stamps     diagnostic build with in-kernel cycle stamps (tools/gemm_stamps.py), not part of the ABI
 #include "common.h"
 #include <stdlib.h>
 
@@ -46,7 +45,6 @@ struct GemmArgs {
     long lda, ldw, ldo, gate_stride;
     int M, N, K;
     int tiles_m, tiles_n;
-    unsigned long long* dbg;  // diagnostic build only (VAR 2): per-wave cycle sums, see uvdbg_gemm_stamps
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -435,7 +433,7 @@ __device__ __forceinline__ void epi_rmw_rows_lds(const GemmArgs& p, char* smem, 
 //       2     W[1] sub (4)                   (A0, W1)           W[0] of K tile t+2
 //       3     A[1] sub (8)                   (A1, W1)           A[0] of K tile t+2
 //       4     -                              (A1, W0)           W[1] of K tile t+2, then vmcnt(6): K tile t+1 landed
-// That is the 4-phase schedule (VAR 0, kept for A/B and for the stamped diagnostic build). The default (VAR 5) merges the
+// That is the 4-phase schedule (VAR 0, kept as the A/B and race-screen reference, tile_cfg 14). The default (VAR 5) merges the
 // phases pairwise - 32 MFMAs per cluster, half as many barriers and cluster ramps per MFMA: +2-4 % measured.
 // Needs N % 256 == 0 rows of W to exist (clamped like A otherwise) and an even K/64 >= 4.
 #define UV_SB() __builtin_amdgcn_s_barrier()
@@ -447,7 +445,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     constexpr int HALF = 16384;      // one half-tile: 128 rows x 128 B
     constexpr int BUF = 4 * HALF;    // A[0] A[1] W[0] W[1]
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned long long r_entry = VAR >= 2 ? __builtin_amdgcn_s_memrealtime() : 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -484,7 +481,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     char* const my_dst = smem + wave * 1024;
     const int nk = p.K / UV_BK;
 #define UV_STAGE(SRC, KT, DSTOFF)                                         \
-    if constexpr (VAR != 3) {                                             \
+    {                                                                     \
         const bf16_t* g0_ = SRC[0] + (long)(KT) * UV_BK;                  \
         const bf16_t* g1_ = SRC[1] + (long)(KT) * UV_BK;                  \
         glds16(g0_, (lds_void*)(my_dst + (DSTOFF)));                      \
@@ -507,24 +504,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4][2], w0[2][2], w1[2][2];
-    if constexpr (VAR == 3) {   // operands never loaded in this experiment: give them finite values
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[j][ks] = *(const bf16x8*)(p.A + (lane + j * 64 + ks * 256) * 8);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) { w0[i][ks] = *(const bf16x8*)(p.W + (lane + i * 64 + ks * 128) * 8); w1[i][ks] = w0[i][ks]; }
-    }
 
 #define UV_RD_A(B, H)                                                                             \
-    if constexpr (VAR != 3) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                     \
         af[j][0] = *(const bf16x8*)(la + (B) * BUF + (H) * HALF + j * 2048 + lx);                 \
         af[j][1] = *(const bf16x8*)(la + (B) * BUF + (H) * HALF + j * 2048 + (lx ^ 64));          \
     }
 #define UV_RD_W(B, H, WF)                                                                         \
-    if constexpr (VAR != 3) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                     \
         WF[i][0] = *(const bf16x8*)(lw + (B) * BUF + (H) * HALF + i * 2048 + lx);                 \
         WF[i][1] = *(const bf16x8*)(lw + (B) * BUF + (H) * HALF + i * 2048 + (lx ^ 64));          \
     }
@@ -599,75 +586,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(1);                                                                \
     UV_MFMA_H(1, 1, w1, 0) UV_MFMA_H(1, 1, w1, 1) UV_MFMA_H(1, 0, w0, 0) UV_MFMA_H(1, 0, w0, 1)   \
     __builtin_amdgcn_s_setprio(0); UV_SCHED(); UV_SB();
-// VAR 2 (diagnostic): VAR 0's schedule with s_memtime stamps at phase start (S), after the first barrier (B) and before the
-// second barrier (E); values are consumed once per K tile in phase 4, where no LDS read is outstanding.
-#define UV_TS(X) UV_SCHED(); X = __builtin_amdgcn_s_memtime(); UV_SCHED();
-#define UV_KTILE2(T, B, O, ST1, ST2)                                                              \
-    UV_TS(tS[0]) UV_RD_W(B, 0, w0) UV_SCHED(); UV_RD_A(B, 0)                                      \
-    if (ST1) UV_STAGE(a_src[1], (T) + 1, (O) * BUF + HALF)                                        \
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                            \
-    UV_SB(); UV_TS(tB[0]) UV_LGKM0(); UV_SCHED();                                                 \
-    UV_MFMA_Q(0, 0, w0) UV_TS(tE[0]) UV_SB();                                                     \
-    UV_TS(tS[1]) UV_RD_W(B, 1, w1)                                                                \
-    if (ST2) UV_STAGE(w_src[0], (T) + 2, (B) * BUF + 2 * HALF)                                    \
-    UV_SB(); UV_TS(tB[1]) UV_LGKM0(); UV_SCHED();                                                 \
-    UV_MFMA_Q(0, 1, w1) UV_TS(tE[1]) UV_SB();                                                     \
-    UV_TS(tS[2]) UV_RD_A(B, 1)                                                                    \
-    if (ST2) UV_STAGE(a_src[0], (T) + 2, (B) * BUF)                                               \
-    UV_SB(); UV_TS(tB[2]) UV_LGKM0(); UV_SCHED();                                                 \
-    UV_MFMA_Q(1, 1, w1) UV_TS(tE[2]) UV_SB();                                                     \
-    UV_TS(tS[3])                                                                                  \
-    if (ST2) {                                                                                    \
-        UV_STAGE(w_src[1], (T) + 2, (B) * BUF + 3 * HALF)                                         \
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                          \
-    } else {                                                                                      \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
-    }                                                                                             \
-    UV_SB(); UV_TS(tB[3])                                                                         \
-    _Pragma("unroll") for (int ph = 0; ph < 3; ++ph) {                                            \
-        cyc[3 * ph] += tB[ph] - tS[ph]; cyc[3 * ph + 1] += tE[ph] - tB[ph]; cyc[3 * ph + 2] += tS[ph + 1] - tE[ph]; \
-    }                                                                                             \
-    if (have_prev) cyc[11] += tS[0] - tE_prev;                                                    \
-    have_prev = true;                                                                             \
-    UV_MFMA_Q(1, 0, w0) UV_TS(tE[3]) UV_SB();                                                     \
-    cyc[9] += tB[3] - tS[3]; cyc[10] += tE[3] - tB[3]; tE_prev = tE[3];
-// VAR 6 (diagnostic): VAR 5's schedule with stamps: per phase {load part incl. waits, barrier 1, MFMA cluster, barrier 2}
-#define UV_KTILE6(T, B, O, ST1, ST2)                                                              \
-    UV_TS(tS[0]) UV_RD_W(B, 0, w0) UV_RD_W(B, 1, w1) UV_RD_A(B, 0)                                \
-    if (ST1) {                                                                                    \
-        UV_STAGE(a_src[1], (T) + 1, (O) * BUF + HALF)                                             \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
-    } else {                                                                                      \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
-    }                                                                                             \
-    UV_LGKM0(); UV_TS(tS[1]) UV_SB(); UV_TS(tB[0])                                                \
-    __builtin_amdgcn_s_setprio(1);                                                                \
-    UV_MFMA_H(0, 0, w0, 0) UV_MFMA_H(0, 0, w0, 1) UV_MFMA_H(0, 1, w1, 0) UV_MFMA_H(0, 1, w1, 1)   \
-    __builtin_amdgcn_s_setprio(0); UV_TS(tE[0]) UV_SB();                                          \
-    UV_TS(tS[2]) UV_RD_A(B, 1)                                                                    \
-    if (ST2) {                                                                                    \
-        UV_STAGE(w_src[0], (T) + 2, (B) * BUF + 2 * HALF)                                         \
-        UV_STAGE(w_src[1], (T) + 2, (B) * BUF + 3 * HALF)                                         \
-        UV_STAGE(a_src[0], (T) + 2, (B) * BUF)                                                    \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
-    } else if (ST1) {                                                                             \
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                          \
-    } else {                                                                                      \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
-    }                                                                                             \
-    UV_LGKM0(); UV_TS(tS[3]) UV_SB(); UV_TS(tB[1])                                                \
-    cyc[0] += tS[1] - tS[0]; cyc[1] += tB[0] - tS[1]; cyc[2] += tE[0] - tB[0]; cyc[3] += tS[2] - tE[0]; \
-    cyc[4] += tS[3] - tS[2]; cyc[5] += tB[1] - tS[3];                                             \
-    if (have_prev) { cyc[6] += tE_prev - tB_prev; cyc[7] += tS[0] - tE_prev; }                    \
-    have_prev = true;                                                                             \
-    __builtin_amdgcn_s_setprio(1);                                                                \
-    UV_MFMA_H(1, 1, w1, 0) UV_MFMA_H(1, 1, w1, 1) UV_MFMA_H(1, 0, w0, 0) UV_MFMA_H(1, 0, w0, 1)   \
-    __builtin_amdgcn_s_setprio(0); UV_TS(tE[1]) UV_SB();                                          \
-    tE_prev = tE[1]; tB_prev = tB[1];
 #define UV_KTILE(T, B, O, ST1, ST2)                                                               \
-    if constexpr (VAR == 6) { UV_KTILE6(T, B, O, ST1, ST2) } else if constexpr (VAR == 5 || VAR == 7) { UV_KTILE5(T, B, O, ST1, ST2) } else if constexpr (VAR >= 2) { UV_KTILE2(T, B, O, ST1, ST2) } else { UV_KTILE0(T, B, O, ST1, ST2) }
+    if constexpr (VAR == 5) { UV_KTILE5(T, B, O, ST1, ST2) } else { UV_KTILE0(T, B, O, ST1, ST2) }
 
-    if constexpr (VAR == 5 || VAR == 6 || VAR == 7) {
+    if constexpr (VAR == 5) {
         // prologue: W0 W1 A0 A1 of K tile 0, W0 W1 A0 of K tile 1; vmcnt(8) = W0 W1 A0 of K tile 0 landed
         UV_STAGE(w_src[0], 0, 2 * HALF) UV_STAGE(w_src[1], 0, 3 * HALF) UV_STAGE(a_src[0], 0, 0) UV_STAGE(a_src[1], 0, HALF)
         UV_STAGE(w_src[0], 1, BUF + 2 * HALF) UV_STAGE(w_src[1], 1, BUF + 3 * HALF) UV_STAGE(a_src[0], 1, BUF)
@@ -681,10 +603,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     UV_SB();
     if (wr == 1) UV_SB();  // the second group runs one barrier behind the first
 
-    unsigned long long tS[4], tB[4], tE[4], tE_prev = 0, tB_prev = 0, cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bool have_prev = false;
-    const unsigned long long t_begin = VAR >= 2 ? __builtin_amdgcn_s_memtime() : 0;
-    const unsigned long long r_begin = VAR >= 2 ? __builtin_amdgcn_s_memrealtime() : 0;
     int t = 0;
     for (; t + 2 < nk; t += 2) {
         UV_KTILE(t, 0, 1, true, true)
@@ -693,26 +611,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     UV_KTILE(t, 0, 1, true, false)
     UV_KTILE(t + 1, 1, 0, false, false)
     if (wr == 0) UV_SB();
-    if constexpr (VAR >= 2) {
-        if (p.dbg && lane == 0) {
-            unsigned long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 16;
-            for (int i = 0; i < 12; ++i) d[i] = cyc[i];
-            d[12] = __builtin_amdgcn_s_memtime() - t_begin;
-            d[14] = __builtin_amdgcn_s_memrealtime() - r_begin;   // 100 MHz ticks: clock = d[12] / d[14] * 100 MHz
-            d[13] = nk;
-            d[8] = r_begin - r_entry;                                  // prologue, 100 MHz ticks
-            d[11] = r_entry;                                           // absolute entry time (dispatch skew between workgroups)
-        }
-    }
-    const unsigned long long r_loop_end = VAR >= 2 ? __builtin_amdgcn_s_memrealtime() : 0;
 
-    if constexpr ((EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) && VAR != 0 && VAR != 7) {
+    if constexpr ((EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) && VAR != 0) {
         // every wave has left the K loop's last LDS reads behind (the loop ends on a barrier both groups take)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         epi_rmw_rows_lds<EPI, F16>(p, smem, acc, m0, n0, wave, lane);
     } else if constexpr (EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) {
-        // VAR 0 / 7 (tile_cfg 14 / 15, A/B references): the fragment-wise read-modify-write epilogue
+        // VAR 0 (tile_cfg 14, the A/B reference): the fragment-wise read-modify-write epilogue
         int mb[32], nb[32];
         f32x4 av[32];
 #pragma unroll
@@ -739,15 +645,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
                         epi_frag<EPI, F16>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], frow, fq);
-    }
-    if constexpr (VAR >= 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (p.dbg && lane == 0) {
-            unsigned long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 16;
-            const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
-            d[9] = r_end - r_loop_end;                                 // epilogue incl. store drain, 100 MHz ticks
-            d[10] = r_end;                                             // absolute end time
-        }
     }
 }
 
@@ -1064,7 +961,7 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias_bf16;
     a.out = out; a.gate = gate; a.gate_tid = gate_tid;
     a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.gate_stride = gate_stride;
-    a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0; a.dbg = nullptr;
+    a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
     if (tile_cfg == 0 && M >= 2048 && N >= 1024 && N % 256 == 0 && K % 128 == 0 && K >= 384) {
         // Large projections: 256x256 tiles on the PERSISTENT 8-wave ping-pong kernel (one workgroup per CU walking its tile
@@ -1075,9 +972,7 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
         const long rounds = tiles / num_cus(), rest = tiles - rounds * num_cus();
         long m_main = tm_full * 256;
         if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) m_main = rounds * num_cus() / tn * 256;
-        static int persist = -1;                       // developer A/B knob: UV_GEMM_PERSIST=0 keeps one tile per workgroup
-        if (persist < 0) { const char* e = getenv("UV_GEMM_PERSIST"); persist = (e && atoi(e) == 0) ? 0 : 1; }
-        if (!persist || m_main / 256 * tn < 2L * num_cus()) {      // under two rounds of work: the one-tile-per-workgroup launch
+        if (m_main / 256 * tn < 2L * num_cus()) {      // under two rounds of work: the one-tile-per-workgroup launch
             if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) return launch_m_split<F16>(a, epilogue, 7, s);
             return launch_by_cfg<F16>(a, epilogue, 7, s);
         }
@@ -1085,7 +980,6 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
     }
     if (tile_cfg == 8) return launch_m_split<F16>(a, epilogue, 7, s);
     if (tile_cfg == 9) return launch_m_split<F16>(a, epilogue, 5, s);
-    if (tile_cfg == 16) return launch_m_split<F16>(a, epilogue, 15, s);
     if (tile_cfg == 18) return launch_m_split<F16>(a, epilogue, 17, s, (long)(M / 256) * 256 < M ? (long)(M / 256) * 256 : 0);
     return launch_by_cfg<F16>(a, epilogue, tile_cfg, s);
 }
@@ -1139,30 +1033,14 @@ static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStrea
         case 7:
             UV_CHECK_ARG(K % 128 == 0 && K >= 256, "uv_gemm_bf16_nt: tile_cfg 7 needs K %% 128 == 0 and K >= 256 (K=%d)", K);
             return launch_8ph<5, F16>(a, epilogue, s);
-        case 14: if constexpr (!F16) return launch_8ph<0>(a, epilogue, s); else break;
-        case 15: if constexpr (!F16) return launch_8ph<7>(a, epilogue, s); else break;
+        case 14: if constexpr (!F16) return launch_8ph<0>(a, epilogue, s); else break;   // 4-phase schedule + fragment-wise RMW epilogue (A/B reference)
         case 17:
             UV_CHECK_ARG(K % 128 == 0 && K >= 384, "uv_gemm_bf16_nt: tile_cfg 17 needs K %% 128 == 0 and K >= 384 (K=%d)", K);
-            return launch_8ph_persist<F16>(a, epilogue, s);   // A/B reference: the default schedule with the fragment-wise RMW epilogue   // the 4-phase-per-K-tile schedule (A/B reference)
+            return launch_8ph_persist<F16>(a, epilogue, s);
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown tile_cfg %d", tile_cfg);
             return -1;
     }
     uv_set_error("uv_gemm_f16_nt: tile_cfg %d is not built for fp16 operands", tile_cfg);
     return -1;
-}
-
-// Diagnostic (not part of the public ABI, used by tools/gemm_bench.py --stamps): the ping-pong kernel with in-kernel cycle
-// stamps. dbg: [tiles][8 waves][16] u64 = per phase {load part + barrier 1, LDS wait + MFMA issue, barrier 2} cycle sums.
-extern "C" int uvdbg_gemm_stamps(const void* A, long lda, const void* W, long ldw, int M, int N, int K, void* out, long ldo,
-                                 unsigned long long* dbg, int variant, void* stream) {
-    GemmArgs a;
-    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = nullptr; a.out = out; a.gate = nullptr; a.gate_tid = nullptr;
-    a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.gate_stride = 0; a.M = M; a.N = N; a.K = K; a.dbg = dbg;
-    a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 255) / 256;
-    auto kern = variant == 3 ? gemm_bf16_8ph_kernel<UV_EPI_BF16, 3> : variant == 6 ? gemm_bf16_8ph_kernel<UV_EPI_BF16, 6> : gemm_bf16_8ph_kernel<UV_EPI_BF16, 2>;
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), 128 * 1024, (hipStream_t)stream, a);
-    UV_CHECK_LAUNCH("uvdbg_gemm_stamps");
-    return 0;
 }
