@@ -88,12 +88,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // GELU(approximate='tanh') of an f32 value (torch upcasts a bf16 tensor, evaluates in f32, rounds once):
 // 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715*x^3). Since 1+tanh(u) = 2/(1+exp(-2u)) this is x / (1 + exp(-2u)):
 // one v_exp_f32 and one v_rcp_f32 (1 ulp each) instead of libm's tanhf (~40 instructions, the dominant cost of the
-// ffn.0 epilogue), and without the cancellation of 1+tanh(u) for x < -2. Limits: u -> -inf gives x*0 = -0, u -> +inf gives x.
+// ffn.0 epilogue), and without the cancellation of 1+tanh(u) for x < -2. The exponent -2u*log2(e) is evaluated as
+// x*(A + B*x^2) with the constants folded (A = -2*log2(e)*sqrt(2/pi), B = A*0.044715): 3 VALU operations instead of 6 in
+// front of the exp; the two forms agree to ~1e-7 relative, far inside the bf16 rounding of the result.
+// Limits: u -> -inf gives x*0 = -0, u -> +inf gives x.
 __device__ __forceinline__ float gelu_tanh_f32(float x) {
-    const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
-    const float kKappa = 0.044715f;
-    const float u = kBeta * (x + kKappa * x * x * x);
-    const float e = __builtin_amdgcn_exp2f(u * -2.8853900817779268f);  // exp(-2u) = 2^(-2u*log2(e))
+    const float kA = -2.3022081986f;    // -2 * log2(e) * sqrt(2/pi)
+    const float kB = -0.1029432396f;    // kA * 0.044715
+    const float q = __builtin_fmaf(x * x, kB, kA);
+    const float e = __builtin_amdgcn_exp2f(x * q);          // exp(-2u)
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 

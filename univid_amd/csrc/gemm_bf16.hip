@@ -24,6 +24,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+const float* uv_zero_page();   // gemm_f32.hip: one 4-KiB page of zeros per device
+
 #define UV_BK 64  // k elements per LDS tile (128-byte rows)
 
 enum {
@@ -42,6 +44,7 @@ struct GemmArgs {
     void* out;
     const float* gate;      // [n_t, gate_stride]  (EPI 4)
     const int32_t* gate_tid;  // [M] row -> gate row (EPI 4), may be nullptr => row 0
+    const float* zeros;       // the library's 4-KiB zero page: what a null bias reads through in the branch-free epilogue
     long lda, ldw, ldo, gate_stride;
     int M, N, K;
     int tiles_m, tiles_n;
@@ -56,16 +59,19 @@ __device__ __forceinline__ void glds16(const void* g, lds_void* l) {
 // One 16x16 accumulator fragment through the fused epilogue. Plain product (D = Wfrag x Afrag): the lane holds
 // n = nb + 4*fq + {0..3} for m = mb + frow. Transposed product (EPI_BF16_T, D = Afrag x Wfrag): m = mb + 4*fq + {0..3}
 // for n = nb + frow.
-template <int EPI, bool F16 = false>
+// FULL: the fragment lies inside the matrix for sure (whole 256x256 tiles of the persistent kernel) - no bounds checks, and a
+// null bias reads zeros instead of branching, so the 32 fragments of a wave form ONE basic block: their loads, transcendental
+// latencies and stores overlap instead of running fragment by fragment behind exec-mask branches.
+template <int EPI, bool F16 = false, bool FULL = false>
 __device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, const f32x4& a, int frow, int fq) {
     if (EPI != UV_EPI_BF16_T) {
         const int m = mb + frow, n = nb + 4 * fq;
-        if (m >= p.M || n >= p.N) return;
+        if (!FULL && (m >= p.M || n >= p.N)) return;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = a[e];
-        if (p.bias) {
-            const u32x2 bb = *(const u32x2*)(p.bias + n);
+        if (FULL || p.bias) {
+            const u32x2 bb = *(const u32x2*)((FULL && !p.bias) ? (const bf16_t*)p.zeros : p.bias + n);
             v[0] += in16<F16>((bf16_t)(bb[0] & 0xffff));
             v[1] += in16<F16>((bf16_t)(bb[0] >> 16));
             v[2] += in16<F16>((bf16_t)(bb[1] & 0xffff));
@@ -99,10 +105,10 @@ __device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, cons
         }
     } else {
         const int n = nb + frow, m = mb + 4 * fq;
-        if (n >= p.N || m >= p.M) return;  // M is padded to a multiple of 4 by the caller's ldo
-        const float b = p.bias ? in16<F16>(p.bias[n]) : 0.f;
+        if (!FULL && (n >= p.N || m >= p.M)) return;  // M is padded to a multiple of 4 by the caller's ldo
+        const float b = FULL ? in16<F16>(*(p.bias ? p.bias + n : (const bf16_t*)p.zeros)) : (p.bias ? in16<F16>(p.bias[n]) : 0.f);
         bf16_t* op = (bf16_t*)p.out + (long)n * p.ldo + m;
-        if (m + 3 < p.M) {
+        if (FULL || m + 3 < p.M) {
             u32x2 o = {pack16_2<F16>(a[0] + b, a[1] + b), pack16_2<F16>(a[2] + b, a[3] + b)};
             *(u32x2*)op = o;
         } else {
@@ -793,7 +799,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_persist_kernel(GemmArgs p) 
                     for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
-                            epi_frag<EPI, F16>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], frow, fq);
+                            epi_frag<EPI, F16, true>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], frow, fq);
         }
         if (!has_next) break;
         m0 = m1; n0 = n1; cur = nxt;
@@ -962,6 +968,8 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
     a.out = out; a.gate = gate; a.gate_tid = gate_tid;
     a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.gate_stride = gate_stride;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
+    a.zeros = uv_zero_page();
+    UV_CHECK_ARG(a.zeros, "uv_gemm_bf16_nt: zero page missing (call uv_init)");
     hipStream_t s = (hipStream_t)stream;
     if (tile_cfg == 0 && M >= 2048 && N >= 1024 && N % 256 == 0 && K % 128 == 0 && K >= 384) {
         // Large projections: 256x256 tiles on the PERSISTENT 8-wave ping-pong kernel (one workgroup per CU walking its tile
