@@ -111,7 +111,7 @@ def cpu_baseline_vae(budget_s=12.0):
     frame alone took 78 s on 256 threads), extrapolated to the 49-frame 720x1280 clip by output pixels (the convolutions'
     FLOPs are proportional to them)."""
     from oracle import wan_vae
-    cores = os.cpu_count() or 1
+    cores = _cpu_threads()
     torch.set_num_threads(cores)
     cfg = wan_vae.FULL_CFG
     vae = wan_vae.WanVAE(wan_vae.make_state_dict(cfg, 0), cfg)
@@ -134,6 +134,13 @@ def cpu_baseline_vae(budget_s=12.0):
                       f"{v.shape[3]}x{v.shape[4]} in {secs:.1f} s on {cores} threads; 49-frame 720x1280 clip extrapolated by output pixels = {full:.0f} s"}
 
 
+def _cpu_threads():
+    """Threads for the CPU baselines. NOT os.cpu_count(): on the 256-hardware-thread hosts of the GPU pool torch's intra-op pool
+    at 256 threads runs the oracle ~80x SLOWER than at 32 (measured: the same VAE chunk 56 s vs 0.7 s; 1.8 s at 64), i.e. the
+    container's usable cores are far fewer than the reported count. 32 is the measured best there; `cores` reports what was used."""
+    return max(1, min(32, os.cpu_count() or 1))
+
+
 def cpu_baseline(cfg, budget_s=15.0):
     """Times the CPU restatement (oracle/, validated bit-exact against the reference modules) on this host.
 
@@ -141,7 +148,7 @@ def cpu_baseline(cfg, budget_s=15.0):
     L_s tokens (L_s picked so the sample takes roughly `budget_s`), extrapolated to a step by the ratio of the
     SURVEY 8(d) FLOP formula (x num_layers, x 2 forwards)."""
     from oracle import wan_dit
-    cores = os.cpu_count() or 1
+    cores = _cpu_threads()
     torch.set_num_threads(cores)
     c1 = dict(cfg, num_layers=1)
     sd = wan_dit.make_state_dict(c1, 0)

@@ -13,6 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle: torch's intra-op pool at the 256 reported hardware threads of the GPU pool's hosts is ~80x slower than at 32
+    # (measured: one VAE decoder chunk 56 s vs 0.7 s), the containers' usable cores being far fewer
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
 
 
 def load_golden(name):

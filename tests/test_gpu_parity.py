@@ -894,7 +894,7 @@ def test_dit_stack_ti2v5b_width_depth_vs_oracle():
     both implementations are recorded per depth (reference stack: model.py:489-497, 30 blocks)."""
     from oracle import wan_dit
     from univid_amd.wan.model import WanModel
-    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
     cfg = dict(wan_dit.TI2V_5B_CFG, num_layers=8)
     with torch.device(DEV):
         m = WanModel.from_config(dict(cfg, model_type="ti2v"))

@@ -118,6 +118,39 @@ __device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, cons
 }
 
 
+// Two column-adjacent 16x16 fragments (columns nb .. nb+15 and nb+16 .. nb+31 of the same 16 rows) through the bf16 / GELU
+// epilogue with 16-BYTE stores: in the MFMA's layout a lane holds 4 consecutive columns (8 bytes of bf16) of each fragment; two
+// v_permlane16_swap exchange the halves between the lane groups fq = 0 <-> 1 and 2 <-> 3 so that every lane ends up with 8
+// CONSECUTIVE columns (fq 0: 0-7, fq 2: 8-15 of the first fragment; fq 1: 16-23, fq 3: 24-31 of the second). One
+// global_store_dwordx4 then writes 64 contiguous bytes per row instead of two dwordx2 stores of 32 bytes each: half the store
+// instructions, twice the segment. Whole tiles only (the persistent kernel); values are those of epi_frag.
+template <int EPI, bool F16>
+__device__ __forceinline__ void epi_pair16(const GemmArgs& p, int mb, int nb, const f32x4& a0, const f32x4& a1, int frow, int fq) {
+    static_assert(EPI == UV_EPI_BF16 || EPI == UV_EPI_GELU_BF16, "16-bit row-major outputs only");
+    const int m = mb + frow;
+    uint32_t w[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int n = nb + 16 * f + 4 * fq;
+        const u32x2 bb = *(const u32x2*)(p.bias ? p.bias + n : (const bf16_t*)p.zeros);
+        const f32x4& a = f ? a1 : a0;
+        float v[4] = {a[0] + in16<F16>((bf16_t)(bb[0] & 0xffff)), a[1] + in16<F16>((bf16_t)(bb[0] >> 16)),
+                      a[2] + in16<F16>((bf16_t)(bb[1] & 0xffff)), a[3] + in16<F16>((bf16_t)(bb[1] >> 16))};
+        if (EPI == UV_EPI_GELU_BF16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f32(round16<F16>(v[e]));
+        }
+        w[f][0] = pack16_2<F16>(v[0], v[1]);
+        w[f][1] = pack16_2<F16>(v[2], v[3]);
+    }
+    // swap lanes 16-31 / 48-63 of the first fragment's words with lanes 0-15 / 32-47 of the second's
+    const auto s0 = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+    const u32x4 o = {(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
+    const int col = ((fq & 1) << 4) + ((fq >> 1) << 3);
+    *(u32x4*)((bf16_t*)p.out + (long)m * p.ldo + nb + col) = o;
+}
+
 // The fp32 read-modify-write epilogues (x += y, x += y*gate) as a D-deep software pipeline over a wave's NF fragments:
 // the token->gate-row indices of all rows are fetched first, then the x / gate loads of fragment f+D are issued before
 // fragment f is stored. Written in this order by hand because the compiler must assume the x stores alias the later
@@ -790,6 +823,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_persist_kernel(GemmArgs p) 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
+        } else if constexpr (EPI == UV_EPI_BF16 || EPI == UV_EPI_GELU_BF16) {
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int hn = 0; hn < 2; ++hn)      // the wave's two column fragments (i = 0, 1) are adjacent: one 16-byte store per lane
+                        epi_pair16<EPI, F16>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32, acc[hn][hm][0][j], acc[hn][hm][1][j], frow, fq);
         } else {
 #pragma unroll
             for (int hm = 0; hm < 2; ++hm)
