@@ -183,8 +183,10 @@ def cpu_baseline(cfg, budget_s=15.0):
     return {"value": 1.0 / full_step_s, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle/wan_dit.block_forward: 1 of {cfg['num_layers']} DiT blocks at L={Ls} tokens "
                       f"(grid {choice}) in {ts:.1f} s on {cores} threads (bf16 autocast dtype flow), extrapolated to one "
-                      f"CFG step at L={L_TOKENS} by the SURVEY 8(d) FLOP ratio (the sample is ~3 % attention FLOPs, the full "
-                      f"step 32 %: the extrapolation assumes the CPU runs both at the same rate)"}
+                      f"CFG step at L={L_TOKENS} by the SURVEY 8(d) FLOP ratio (self-attention is "
+                      f"{100 * self_attn_flops(Ls, cfg['dim']) / block_flops(Ls):.0f} % of the sample's FLOPs and "
+                      f"{100 * self_attn_flops(L_TOKENS, cfg['dim']) / block_flops(L_TOKENS):.0f} % of a full-size block's: where they "
+                      f"differ the extrapolation assumes the CPU runs attention and GEMMs at the same rate)"}
 
 
 def main():
