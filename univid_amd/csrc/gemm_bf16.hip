@@ -151,6 +151,23 @@ __device__ __forceinline__ void epi_pair16(const GemmArgs& p, int mb, int nb, co
     *(u32x4*)((bf16_t*)p.out + (long)m * p.ldo + nb + col) = o;
 }
 
+// The transposed 16-bit epilogue (V^T) with 16-byte stores, same exchange as epi_pair16: in the transposed product a lane holds 4
+// consecutive ROWS m of one column n, and the wave's row fragments j and j+1 (rows mb .. mb+15 and mb+16 .. mb+31) are adjacent
+// along the contiguous axis of the transposed output; after two v_permlane16_swap every lane owns 8 consecutive m of its n:
+// 64 contiguous bytes per output row and instruction instead of 32. Whole tiles only.
+template <bool F16>
+__device__ __forceinline__ void epi_pair16_T(const GemmArgs& p, int mb, int nb, const f32x4& a0, const f32x4& a1, int frow, int fq) {
+    const int n = nb + frow;
+    const float b = in16<F16>(*(p.bias ? p.bias + n : (const bf16_t*)p.zeros));
+    uint32_t w0[2] = {pack16_2<F16>(a0[0] + b, a0[1] + b), pack16_2<F16>(a0[2] + b, a0[3] + b)};
+    uint32_t w1[2] = {pack16_2<F16>(a1[0] + b, a1[1] + b), pack16_2<F16>(a1[2] + b, a1[3] + b)};
+    const auto s0 = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
+    const u32x4 o = {(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
+    const int row = ((fq & 1) << 4) + ((fq >> 1) << 3);
+    *(u32x4*)((bf16_t*)p.out + (long)n * p.ldo + mb + row) = o;
+}
+
 // The fp32 read-modify-write epilogues (x += y, x += y*gate) as a D-deep software pipeline over a wave's NF fragments:
 // the token->gate-row indices of all rows are fetched first, then the x / gate loads of fragment f+D are issued before
 // fragment f is stored. Written in this order by hand because the compiler must assume the x stores alias the later
@@ -831,6 +848,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_persist_kernel(GemmArgs p) 
 #pragma unroll
                     for (int hn = 0; hn < 2; ++hn)      // the wave's two column fragments (i = 0, 1) are adjacent: one 16-byte store per lane
                         epi_pair16<EPI, F16>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32, acc[hn][hm][0][j], acc[hn][hm][1][j], frow, fq);
+        } else if constexpr (EPI == UV_EPI_BF16_T) {
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+                for (int j = 0; j < 4; j += 2)          // row fragments j, j+1 are adjacent along the transposed output's rows
+#pragma unroll
+                    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            epi_pair16_T<F16>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32 + i * 16, acc[hn][hm][i][j], acc[hn][hm][i][j + 1], frow, fq);
         } else {
 #pragma unroll
             for (int hm = 0; hm < 2; ++hm)
@@ -889,6 +916,8 @@ template <bool F16 = false>
 static int launch_8ph_persist(const GemmArgs& a0, int epi, hipStream_t stream) {
     GemmArgs a = a0;
     UV_CHECK_ARG(a.M % 256 == 0 && a.N % 256 == 0, "uv_gemm_bf16_nt: the persistent kernel needs whole 256x256 tiles (M=%d N=%d)", a.M, a.N);
+    UV_CHECK_ARG(a.ldo % 8 == 0 || (epi != UV_EPI_BF16_T && epi != UV_EPI_BF16 && epi != UV_EPI_GELU_BF16),
+                 "uv_gemm_bf16_nt: the persistent kernel stores 16 bytes per lane: ldo=%ld must be a multiple of 8 elements", a.ldo);
     a.tiles_m = a.M / 256;
     a.tiles_n = a.N / 256;
     const int tiles = a.tiles_m * a.tiles_n;
@@ -1012,7 +1041,8 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
     a.zeros = uv_zero_page();
     UV_CHECK_ARG(a.zeros, "uv_gemm_bf16_nt: zero page missing (call uv_init)");
     hipStream_t s = (hipStream_t)stream;
-    if (tile_cfg == 0 && M >= 2048 && N >= 1024 && N % 256 == 0 && K % 128 == 0 && K >= 384) {
+    if (tile_cfg == 0 && M >= 2048 && N >= 1024 && N % 256 == 0 && K % 128 == 0 && K >= 384 &&
+        (ldo % 8 == 0 || epilogue == UV_EPI_BF16_T || epilogue >= UV_EPI_F32_FROM_BF16)) {
         // Large projections: 256x256 tiles on the PERSISTENT 8-wave ping-pong kernel (one workgroup per CU walking its tile
         // list). It takes whole tiles only; rows beyond the last multiple of 256 - and, when the tile count is just above a
         // whole number of rounds, the rows of that partial round - run as 128x128 tiles on the small-tile kernel.
@@ -1021,7 +1051,8 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
         const long rounds = tiles / num_cus(), rest = tiles - rounds * num_cus();
         long m_main = tm_full * 256;
         if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) m_main = rounds * num_cus() / tn * 256;
-        if (m_main / 256 * tn < 2L * num_cus()) {      // under two rounds of work: the one-tile-per-workgroup launch
+        // (also when the transposed output's leading dimension does not allow the persistent kernel's 16-byte stores)
+        if (m_main / 256 * tn < 2L * num_cus() || (epilogue == UV_EPI_BF16_T && ldo % 8 != 0)) {      // under two rounds of work: the one-tile-per-workgroup launch
             if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) return launch_m_split<F16>(a, epilogue, 7, s);
             return launch_by_cfg<F16>(a, epilogue, 7, s);
         }
