@@ -1407,6 +1407,32 @@ def test_sequence_parallel_forward_over_rccl(world):
     assert all(ok and refused for _, ok, refused, _ in res), res
 
 
+def _rccl_one_rank_worker(rank, world, port, q, nccl=True):
+    dist = _init_group(rank, world, port, nccl)
+    try:
+        from univid_amd import parallel
+        x = torch.arange(12, dtype=torch.float32, device=DEV).view(3, 4)
+        dist.barrier()
+        got = parallel.gather_latents([x, x + 1], 2)
+        t = torch.tensor([1.5], device=DEV, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sp = parallel.SeqParallel()
+        out = torch.empty(8, 4, dtype=BF16, device=DEV)
+        sp.heads_to_tokens(torch.ones(8, 4, dtype=BF16, device=DEV), 8, out)
+        q.put((rank, dist.get_backend(), bool(torch.equal(got[0], x) and torch.equal(got[1], x + 1) and float(t) == 1.5 and bool((out == 1).all()))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_process_group_on_this_box():
+    """RCCL itself on whatever the box has: a ONE-rank process group on backend "nccl" (init with device_id, barrier,
+    all_gather through parallel.gather_latents, all_reduce MAX of the float64 timing scalar bench.py reduces, the size-1
+    sequence-parallel exchange). The multi-rank variants above need one GPU per rank; this one runs everywhere and catches an
+    RCCL / IPC environment that cannot even initialise."""
+    res = _spawn(_rccl_one_rank_worker, 1, nccl=True)
+    assert res == [(0, "nccl", True)], res
+
+
 def _cfgp_gpu_worker(rank, world, port, q, nccl=False):
     dist = _init_group(rank, world, port, nccl)
     try:
