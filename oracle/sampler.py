@@ -15,8 +15,8 @@ from . import unipc, wan_dit
 
 def masks_like(tensors, zero=False):
     """utils.py:172-199 without the random branch (generator=None in both WanTI2V loops)."""
-    out1 = [torch.ones(u.shape, dtype=u.dtype) for u in tensors]
-    out2 = [torch.ones(u.shape, dtype=u.dtype) for u in tensors]
+    out1 = [torch.ones(u.shape, dtype=u.dtype, device=u.device) for u in tensors]
+    out2 = [torch.ones(u.shape, dtype=u.dtype, device=u.device) for u in tensors]
     if zero:
         for u, v in zip(out1, out2):
             u[:, 0] = 0
@@ -88,7 +88,7 @@ def denoise(sd, cfg, noise, context, context_null, steps, shift, guide_scale, z=
         return wan_dit.dit_forward(sd, cfg, [latent], tvec, ctx, seq_len, context_scale_fn=hook)[0]
 
     for t in timesteps:
-        ts = torch.stack([t])
+        ts = torch.stack([t]).to(noise.device)          # (device move: a no-op on the CPU)
         temp = (mask2[0][0][:, ::2, ::2] * ts).flatten()                                # :373
         temp = torch.cat([temp, temp.new_ones(seq_len - temp.size(0)) * ts])
         tvec = temp.unsqueeze(0)

@@ -90,7 +90,7 @@ class FlowUniPC:
         x_t_ = c["sigma_t"] / c["sigma_s0"] * sample - c["alpha_t"] * c["h_phi_1"] * m0
         if order == 2:
             d1s = torch.stack([(self.model_outputs[-2] - m0) / c["rks"][0]], dim=1)
-            pred_res = _einsum_ac(torch.tensor([0.5], dtype=sample.dtype), d1s)      # :460-461, 471
+            pred_res = _einsum_ac(torch.tensor([0.5], dtype=sample.dtype, device=sample.device), d1s)      # :460-461, 471
         else:
             pred_res = 0
         return (x_t_ - c["alpha_t"] * c["B_h"] * pred_res).to(sample.dtype)
@@ -101,9 +101,9 @@ class FlowUniPC:
         si = self.step_index
         c = self._coeffs(si, si - 1, order, [si - (i + 1) for i in range(1, order)])
         if order == 1:
-            rhos_c = torch.tensor([0.5], dtype=last_sample.dtype)                   # :606-607
+            rhos_c = torch.tensor([0.5], dtype=last_sample.dtype, device=last_sample.device)                   # :606-607
         else:
-            rhos_c = torch.linalg.solve(c["R"], c["b"]).to(last_sample.dtype)       # :609
+            rhos_c = torch.linalg.solve(c["R"], c["b"]).to(last_sample.dtype).to(last_sample.device)       # :609 (solved on the host)
         x_t_ = c["sigma_t"] / c["sigma_s0"] * last_sample - c["alpha_t"] * c["h_phi_1"] * m0
         if order == 2:
             d1s = torch.stack([(self.model_outputs[-2] - m0) / c["rks"][0]], dim=1)
