@@ -1377,6 +1377,7 @@ def _init_group(rank, world, port, nccl):
     """gloo: the ranks share the test box's one GPU (exchanges go through the host-memory emulation of univid_amd.parallel);
     nccl: one GPU per rank, RCCL over xGMI - the transport the product uses (runs where the box has >= `world` GPUs)."""
     import torch.distributed as dist
+    torch.set_num_threads(8)          # spawned workers: several processes share the host (and 256 threads each is pathological)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if nccl:
