@@ -229,6 +229,8 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: start one rank per GPU "
                          f"(`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`)")
     import torch.distributed as dist
+    # host threads: the loop's host side is scalar sampler algebra; never let N ranks open N x 256-thread pools on one host
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(world, 1))))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
