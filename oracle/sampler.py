@@ -83,7 +83,7 @@ def denoise(sd, cfg, noise, context, context_null, steps, shift, guide_scale, z=
                             text_weight_cfg.get("schedule", "cosine"))
             fwd_counter[0] += 1
             if w != 1.0:
-                m = context_mask((1, cfg["text_len"], cfg["dim"]), w, text_weight_cfg.get("bagel_sequence_length", 128))
+                m = context_mask((1, cfg["text_len"], cfg["dim"]), w, text_weight_cfg.get("bagel_sequence_length", 128)).to(noise.device)
                 hook = lambda layer: m
         return wan_dit.dit_forward(sd, cfg, [latent], tvec, ctx, seq_len, context_scale_fn=hook)[0]
 

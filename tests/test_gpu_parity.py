@@ -1021,6 +1021,60 @@ def test_config2_full_run_50_steps_vs_eager_oracle():
 CONFIG2_RUN_GATE = (2.5e-2, 4.5e-3)
 
 
+def test_full_model_i2v_and_text_weight_hook_vs_eager_oracle():
+    """The two other loop variants on the FULL 30-block TI2V-5B model at config 2's shape, 8 UniPC steps each, against the
+    oracle's loop on torch-ROCm eager: (a) i2v - first latent frame pinned to z, per-token timesteps {0, t} (textimage2video.py
+    :548-601); (b) UniVid's dynamic text-weight hook through Wan22ContextWrapper - the per-forward counter, the per-layer
+    bf16 context mask and the un-fused reference-signature cross-attention path at width 3072 (model_pipeline.py:1699-1886)."""
+    import logging
+    from oracle import sampler, wan_dit
+    from univid_amd.model_pipeline import CrossAttentionConfig, Wan22ContextWrapper
+    from univid_amd.wan.model import WanModel
+    from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+    cfg = dict(wan_dit.TI2V_5B_CFG)
+    with torch.device(DEV):
+        m = WanModel.from_config(dict(cfg, model_type="ti2v"))
+    m = m.eval().requires_grad_(False)
+    m.init_weights(0)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    g = torch.Generator(device=DEV).manual_seed(43)
+    noise = torch.randn(48, 13, 30, 52, device=DEV, generator=g)
+    z = torch.randn(48, 1, 30, 52, device=DEV, generator=g)
+    ctx = [torch.randn(77, cfg["text_dim"], device=DEV, generator=g) * 0.1]
+    ctx_null = [torch.randn(12, cfg["text_dim"], device=DEV, generator=g) * 0.1]
+    pipe = WanTI2V(TI2VConfig, model=m, device=DEV)
+    steps = 8
+    with torch.no_grad():
+        got = pipe.denoise(noise, ctx, ctx_null, steps, 5.0, 5.0, z=z)
+        ref = sampler.denoise(sd, cfg, noise, ctx, ctx_null, steps, 5.0, 5.0, z=z)
+    assert torch.equal(got[:, 0], z[:, 0]), "i2v must keep the first latent frame pinned to z"
+    i2v = _rel_rms(got, ref)
+    with torch.no_grad():
+        plain_hip = pipe.denoise(noise, ctx, ctx_null, steps, 5.0, 5.0)
+    ccfg = CrossAttentionConfig(total_sampling_steps=steps, text_weight_transition_ratio=0.5, use_dynamic_text_weight=True)
+    wr = Wan22ContextWrapper(pipe, None, logging.getLogger("t"), ccfg)
+    wr.set_bagel_context(torch.zeros(1, 4, 8))
+    with torch.no_grad():
+        hooked = wr.generate(input_prompt="", size=(832, 480), frame_num=49, shift=5.0, sampling_steps=steps, guide_scale=5.0,
+                             prompt_embeds=ctx, negative_prompt_embeds=ctx_null, noise=noise, decode=False)
+        ref_h = sampler.denoise(sd, cfg, noise, ctx, ctx_null, steps, 5.0, 5.0, text_weight_cfg=dict(total_steps=steps, ratio=0.5))
+        plain = sampler.denoise(sd, cfg, noise, ctx, ctx_null, steps, 5.0, 5.0)
+    wr.restore_original_methods()
+    hook, effect, plain_hip_vs_hooked = _rel_rms(hooked, ref_h), _rel_rms(plain, ref_h), _rel_rms(plain_hip, ref_h)
+    record_margin("full 30-block model, [48,13,30,52], 8 steps: i2v and text-weight hook, rel rms of the final latent vs eager oracle",
+                  i2v=i2v, hook=hook, hook_effect_in_the_oracle=effect, plain_hip_vs_hooked_oracle=plain_hip_vs_hooked,
+                  plain=_rel_rms(plain_hip, plain))
+    assert i2v < FULL_VARIANT_GATE and hook < FULL_VARIANT_GATE, (i2v, hook)
+    # the hook's effect on the result (9.8e-3 in the oracle at these random weights) is of the size of the CFG-amplified bf16 noise
+    # between the two implementations (7.6e-3): the discriminating check is that the hooked HIP run is closer to the hooked oracle
+    # than the un-hooked HIP run is (measured 7.64e-3 vs 9.81e-3)
+    assert hook < 0.9 * plain_hip_vs_hooked, "the hooked HIP run must follow the hooked oracle, not the plain one"
+
+
+# measured on MI355X (profiles/r02_parity_margins.json): i2v 7.5e-3, hook 7.6e-3 after 8 steps (CFG x5 on 3.5e-3 per forward); x 1.5
+FULL_VARIANT_GATE = 1.15e-2
+
+
 def test_text_weight_hook_path_matches_oracle():
     """UniVid's per-layer context hook (model_pipeline.py:1742-1810, 1844-1886) through the product's wrapper."""
     import logging
