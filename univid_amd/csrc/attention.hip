@@ -660,21 +660,24 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int r = lane & 31, h = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    int vb = blockIdx.x;
-    if constexpr (XCD) {
-        const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
-        const int x = vb & 7, j = vb >> 3;
-        vb = x * per + min(x, rem) + j;
-    }
-    // ids [0, n12 * BH): the 12-unit blocks of all (sample, head) pairs, head-major; then the 8-unit blocks
+    // Workgroup b runs on XCD b % 8 as the (b / 8)-th workgroup dealt to it. Every XCD gets an equal share of the 12-unit blocks
+    // FIRST and of the 8-unit blocks AFTER them (so each CU ends on short workgroups), and within each kind a contiguous range of
+    // (sample, head, block) ids (so a head's K / V^T streams through one L2). Needs both block totals to divide by 8 (24 heads do);
+    // otherwise plain id order, which keeps "12-unit blocks first" but not the L2 locality.
     const int nbh = p.H * p.batch, n8 = p.q_blocks - p.n12;
+    const int tot12 = p.n12 * nbh, tot8 = n8 * nbh;
+    int id = blockIdx.x;                 // < tot12: a 12-unit block, else 8-unit block number id - tot12
+    if (XCD && (tot12 & 7) == 0 && (tot8 & 7) == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, c12 = tot12 >> 3, c8 = tot8 >> 3;
+        id = j < c12 ? x * c12 + j : tot12 + x * c8 + (j - c12);
+    }
     int bh, u0, units;
-    if (vb < p.n12 * nbh) {
-        bh = vb / p.n12;
-        u0 = (vb - bh * p.n12) * 12;
+    if (id < tot12) {
+        bh = id / p.n12;
+        u0 = (id - bh * p.n12) * 12;
         units = 12;
     } else {
-        const int v2 = vb - p.n12 * nbh;
+        const int v2 = id - tot12;
         bh = v2 / n8;
         u0 = p.n12 * 12 + (v2 - bh * n8) * 8;
         units = 8;
@@ -929,14 +932,15 @@ static AttnKernel attn_select(int Lk, int head_dim, long ldk, long ldvt, bool f1
 }
 
 // Cut of a (sample, head)'s NWU = ceil(Lq / 32) query units into n12 blocks of 12 units followed by n8 blocks of 8 units for
-// flash_attn_fwd12_kernel. Model: a 12-unit workgroup takes time 1, an 8-unit one T8 = 0.725 (measured: three waves per SIMD
-// deliver 1.085x the throughput of two), CUs pick workgroups up in id order (12-unit blocks first = longest-first list
-// scheduling); the cut with the smallest simulated makespan wins, ties go to fewer workgroups.
+// flash_attn_fwd12_kernel. Model: a 12-unit workgroup takes time 1, an 8-unit one T8 = 0.76 (measured), every XCD's CUs pick
+// their workgroups up in id order (12-unit blocks first = longest-first list scheduling); the cut with the smallest simulated
+// makespan wins, ties go to fewer workgroups. Measured at the DiT shape (batch 2): 26 + 6 blocks 2.86 ms against 2.90 ms for
+// 30 + 0; mixes with more 8-unit blocks lose (24 + 9: 3.03 ms). At batch 1 the model picks 30 + 0 (768 workgroups = 3 rounds).
 static void attn12_cut(int Lq, int heads_total, int* n12_out, int* n8_out) {
     const int nwu = (Lq + UV_ATT_QW - 1) / UV_ATT_QW, ncu = uv_num_cus();
     static int memo_key[2] = {0, 0}, memo_val[2] = {0, 0};
     if (memo_key[0] == nwu && memo_key[1] == heads_total * 1024 + ncu) { *n12_out = memo_val[0]; *n8_out = memo_val[1]; return; }
-    const double T8 = 0.725;
+    const double T8 = 0.76;   // measured: all-8-unit cut 0.365 ms per round of workgroups, all-12-unit cut 0.48 ms (batch 2, L = 11 440)
     int best12 = (nwu + 11) / 12, best8 = 0;
     double best = 1e30;
     for (int n8 = 0; n8 * 8 < nwu + 8; ++n8) {
