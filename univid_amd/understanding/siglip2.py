@@ -208,21 +208,22 @@ class Siglip2VisionModel(nn.Module):
         """One captured HIP graph per (image count, grid): the ~150 launches of a 12-layer tower take ~3-4 us of host time each,
         about as long as the kernels themselves at 64 frames x 256 patches; replaying them as one graph removes the gaps.
         Static input / output buffers; the kernels and their order are those of the eager path (bit-identical)."""
-        key = (G, hw, px.shape[1], self._op)
-        ent = self._graphs.get(key)
-        if ent is None:
-            buf = torch.empty_like(px)
+        key = (G, hw, px.shape[1], self._op, px.device)
+        with torch.cuda.device(px.device):                      # torch's capture stream belongs to the current device
+            ent = self._graphs.get(key)
+            if ent is None:
+                buf = torch.empty_like(px)
+                buf.copy_(px)
+                self._pooled_group(buf, hw, G)                  # eager warm-up: scratch, function attributes
+                torch.cuda.synchronize(px.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    z = self._pooled_group(buf, hw, G)
+                ent = self._graphs[key] = (g, buf, z)
+            g, buf, z = ent
             buf.copy_(px)
-            self._pooled_group(buf, hw, G)                      # eager warm-up: scratch, function attributes
-            torch.cuda.synchronize(px.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                z = self._pooled_group(buf, hw, G)
-            ent = self._graphs[key] = (g, buf, z)
-        g, buf, z = ent
-        buf.copy_(px)
-        g.replay()
-        return z.clone()
+            g.replay()
+            return z.clone()
 
     def _pooled_group(self, px, hw, G):
         """px fp32 [G*n, 3*p*p]: the patches of G images with the same (h, w) grid -> pooler_output [G, h] fp32."""

@@ -107,7 +107,10 @@ class _GraphedPair:
             tid = torch.cat([one, one]).contiguous()
         ctx = [context[0], context_null[0]]
         self.lat.copy_(latent)
-        with torch.no_grad():
+        self.dev = dev
+        # capture and replay with the latent's device current: torch's capture stream belongs to the current device, and the
+        # kernels follow the device of their tensors (a model on cuda:1 in a process whose current device is cuda:0)
+        with torch.no_grad(), torch.cuda.device(dev):
             # eager warm-up on the capture inputs: weight preparation, context cache, scratch buffers, function attributes
             model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid))
             torch.cuda.synchronize(dev)
@@ -120,9 +123,10 @@ class _GraphedPair:
                 self.out = model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid))
 
     def __call__(self, latent, t):
-        self.lat.copy_(latent)
-        self.tvals[-1:].fill_(t)             # the value travels as a kernel argument (no host buffer to race with); row 0 stays 0 for i2v
-        self.graph.replay()
+        with torch.cuda.device(self.dev):
+            self.lat.copy_(latent)
+            self.tvals[-1:].fill_(t)         # the value travels as a kernel argument (no host buffer to race with); row 0 stays 0 for i2v
+            self.graph.replay()
         return self.out[0], self.out[1]      # static outputs: consumed by the sampler update before the next replay
 
 
