@@ -83,20 +83,54 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
     const int Hlim = p.up ? 2 * p.Hin : p.Hin, Wlim = p.up ? 2 * p.Win : p.Win;
     const long frame = (long)p.Hin * p.Win * p.ld_in;
 
+    // Fast gather addressing (every convolution except the 2x-upsampling ones): a piece's source for tap (dt, dh, dw) is its
+    // pointer for tap (0, 0, 0) plus an offset that is THE SAME for every lane, and whether the tap falls inside the input is a
+    // property of (piece, tap) that does not change along K. So per piece ONE base pointer and ONE bit mask over the <= 27 taps
+    // are computed up front, and staging a k-tile costs a bit test, a select against the zero page and a 64-bit add per piece -
+    // instead of re-deriving (t, h, w), three bounds checks and a 64-bit multiply-add behind an exec-mask branch, per piece and
+    // k-tile (the compiled loop spent ~150 VALU / SALU instructions and 4 divergent branches there per 128 MFMAs).
+    const bool fast = !p.up && p.kt * p.kh * p.kw <= 32;
+    const float* a_base[A_INSTR];
+    unsigned a_mask[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int it0 = a_t[i] * p.st + p.t_off, ih0 = a_h[i] * p.sh - p.ph, iw0 = a_w[i] * p.sw - p.pw;
+        a_base[i] = p.in + (long)it0 * frame + ((long)ih0 * p.Win + iw0) * p.ld_in + a_c[i];
+        unsigned mk = 0;
+        if (fast) {
+            for (int dt = 0, tap = 0; dt < p.kt; ++dt)
+                for (int dh = 0; dh < p.kh; ++dh)
+                    for (int dw = 0; dw < p.kw; ++dw, ++tap) {
+                        const bool ok = (unsigned)(it0 + dt) < (unsigned)p.Tin && (unsigned)(ih0 + dh) < (unsigned)p.Hin &&
+                                        (unsigned)(iw0 + dw) < (unsigned)p.Win;
+                        mk |= (unsigned)ok << tap;
+                    }
+        }
+        a_mask[i] = mk;
+    }
+
     // running (tap, channel) position of the NEXT k-tile to stage; a k-tile (32 channels) never straddles taps
-    int s_ci = 0, s_dt = 0, s_dh = 0, s_dw = 0;
+    int s_ci = 0, s_dt = 0, s_dh = 0, s_dw = 0, s_tap = 0;
+    long s_off = 0;                      // element offset of the current tap from tap (0, 0, 0): dt * frame + (dh * Win + dw) * ld_in
 #define UV_CONV_STAGE(KT, BUF)                                                                                        \
     do {                                                                                                              \
         char* sbase = smem + (BUF) * STAGE;                                                                           \
-        _Pragma("unroll") for (int i = 0; i < A_INSTR; ++i) {                                                         \
-            const int it = a_t[i] * p.st + s_dt + p.t_off;                                                            \
-            int ih = a_h[i] * p.sh + s_dh - p.ph;                                                                     \
-            int iw = a_w[i] * p.sw + s_dw - p.pw;                                                                     \
-            const bool ok = (unsigned)it < (unsigned)p.Tin && (unsigned)ih < (unsigned)Hlim &&                        \
-                            (unsigned)iw < (unsigned)Wlim;                                                            \
-            if (p.up) { ih >>= 1; iw >>= 1; }                                                                         \
-            const float* src = ok ? p.in + it * frame + ((long)ih * p.Win + iw) * p.ld_in + s_ci + a_c[i] : p.zeros;  \
-            __builtin_amdgcn_global_load_lds(src, (lds_void_c*)(sbase + (i * NW + wave) * 1024), 16, 0, 0);           \
+        if (fast) {                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < A_INSTR; ++i) {                                                     \
+                const float* src = ((a_mask[i] >> s_tap) & 1u) ? a_base[i] + (s_off + s_ci) : p.zeros;                \
+                __builtin_amdgcn_global_load_lds(src, (lds_void_c*)(sbase + (i * NW + wave) * 1024), 16, 0, 0);       \
+            }                                                                                                         \
+        } else {                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < A_INSTR; ++i) {                                                     \
+                const int it = a_t[i] * p.st + s_dt + p.t_off;                                                        \
+                int ih = a_h[i] * p.sh + s_dh - p.ph;                                                                 \
+                int iw = a_w[i] * p.sw + s_dw - p.pw;                                                                 \
+                const bool ok = (unsigned)it < (unsigned)p.Tin && (unsigned)ih < (unsigned)Hlim &&                    \
+                                (unsigned)iw < (unsigned)Wlim;                                                        \
+                if (p.up) { ih >>= 1; iw >>= 1; }                                                                     \
+                const float* src = ok ? p.in + it * frame + ((long)ih * p.Win + iw) * p.ld_in + s_ci + a_c[i] : p.zeros; \
+                __builtin_amdgcn_global_load_lds(src, (lds_void_c*)(sbase + (i * NW + wave) * 1024), 16, 0, 0);       \
+            }                                                                                                         \
         }                                                                                                             \
         const int koff = (KT) * 32;                                                                                   \
         _Pragma("unroll") for (int i = 0; i < W_INSTR; ++i) {                                                         \
@@ -107,7 +141,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
         s_ci += 32;                                                                                                   \
         if (s_ci >= p.Cin) {                                                                                          \
             s_ci = 0;                                                                                                 \
+            ++s_tap;                                                                                                  \
             if (++s_dw == p.kw) { s_dw = 0; if (++s_dh == p.kh) { s_dh = 0; ++s_dt; } }                               \
+            s_off = (long)s_dt * frame + ((long)s_dh * p.Win + s_dw) * p.ld_in;                                       \
         }                                                                                                             \
     } while (0)
 
