@@ -154,6 +154,11 @@ int uv_unipc_corrector(const float* x_last, const float* m0, const float* m_prev
 /* multistep_uni_p_bh_update (fm_solvers_unipc.py:397-486). */
 int uv_unipc_predictor(const float* x, const float* m0, const float* m_prev, float* out, float r, float c1, float c2,
                        float rk, int order, long n, void* stream);
+/* DPM-Solver++ update of sample_solver='dpm++' (textimage2video.py:343-351): dpm_solver_first_order_update (fm_solvers.py:417-485,
+ * order 1) and multistep_dpm_solver_second_order_update, midpoint (fm_solvers.py:488-595, order 2; m1 = the older x0), with the
+ * host-computed fp32 scalars r = sigma_t/sigma_s0, c = alpha_t*(exp(-h)-1), inv_r0 = 1/r0. */
+int uv_dpmpp_update(const float* x, const float* m0, const float* m1, float* out, float r, float c, float inv_r0, int order,
+                    long n, void* stream);
 
 /* ---- VAE (fp32, channels-last [T, H, W, C]) -------------------------------------------------------------------- */
 /* Causal 3D / 2D convolution as implicit GEMM on the exact-f32 MFMA. Replaces CausalConv3d (vae2_2.py:17-42) and the

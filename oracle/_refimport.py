@@ -168,7 +168,8 @@ def load_reference():
     model.flash_attention = fa_cpu
     vae = _load("uvref_modules.vae2_2", os.path.join(_MODDIR, "vae2_2.py"), "uvref_modules")
     unipc = _load("uvref_unipc", os.path.join(_UTILDIR, "fm_solvers_unipc.py"))
-    ns = types.SimpleNamespace(attention=attention, model=model, vae=vae, unipc=unipc)
+    dpm = _load("uvref_dpm", os.path.join(_UTILDIR, "fm_solvers.py"))
+    ns = types.SimpleNamespace(attention=attention, model=model, vae=vae, unipc=unipc, dpm=dpm)
     _cache["ns"] = ns
     return ns
 

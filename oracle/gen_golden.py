@@ -19,7 +19,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import _refimport, projector, sampler, siglip2, t5, unipc, wan_dit, wan_vae  # noqa: E402
+from oracle import _refimport, dpmpp, projector, sampler, siglip2, t5, unipc, wan_dit, wan_vae  # noqa: E402
 from univid_amd import detinit  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -128,7 +128,43 @@ def gen_unipc(ns):
     save("unipc", x=x, model_outputs=outs, trajectory=torch.stack(traj), **arrs)
 
 
-def gen_sampler(ns, steps=10, keep=(0, 1, 2, 5, 9), name="sampler_tiny"):
+def gen_dpmpp(ns):
+    """FlowDPMSolverMultistepScheduler as WanTI2V builds it for sample_solver='dpm++' (textimage2video.py:343-351)."""
+    print("dpmpp")
+    S = ns.dpm.FlowDPMSolverMultistepScheduler
+    arrs = {}
+    for steps, shift in ((50, 5.0), (10, 5.0), (20, 3.0), (2, 5.0), (1, 5.0)):
+        sch = S(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        sig = ns.dpm.get_sampling_sigmas(steps, shift)
+        ts, _ = ns.dpm.retrieve_timesteps(sch, device="cpu", sigmas=sig)
+        mine = dpmpp.FlowDPMpp(1000, shift=1)
+        assert np.array_equal(sig, dpmpp.get_sampling_sigmas(steps, shift))
+        tm = mine.set_timesteps(sigmas=dpmpp.get_sampling_sigmas(steps, shift))
+        assert torch.equal(tm, ts) and torch.equal(mine.sigmas, sch.sigmas)
+        arrs[f"timesteps_{steps}_{shift}"] = ts
+        arrs[f"sigmas_{steps}_{shift}"] = sch.sigmas
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 48, 2, 6, 8, generator=g)
+    for steps in (10, 20, 2, 1):              # < 15 steps and >= 15 steps take different lower-order rules (fm_solvers.py:771-777)
+        outs = torch.randn(steps, 1, 48, 2, 6, 8, generator=g)
+        sch = S(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        ts, _ = ns.dpm.retrieve_timesteps(sch, device="cpu", sigmas=ns.dpm.get_sampling_sigmas(steps, 5.0))
+        mine = dpmpp.FlowDPMpp(1000, shift=1)
+        mine.set_timesteps(sigmas=dpmpp.get_sampling_sigmas(steps, 5.0))
+        lat, latm, traj = x, x, []
+        for i, t in enumerate(ts):
+            with torch.amp.autocast("cuda", dtype=torch.bfloat16):
+                lat = sch.step(outs[i], t, lat, return_dict=False)[0]
+            latm = mine.step(outs[i], t, latm)
+            assert torch.equal(lat, latm), f"oracle DPM++ != reference at step {i} of {steps}"
+            traj.append(lat)
+        assert torch.isfinite(lat).all()
+        arrs[f"model_outputs_{steps}"] = outs
+        arrs[f"trajectory_{steps}"] = torch.stack(traj)
+    save("dpmpp", x=x, **arrs)
+
+
+def gen_sampler(ns, steps=10, keep=(0, 1, 2, 5, 9), name="sampler_tiny", solver="unipc"):
     """t2v + i2v trajectories of the tiny DiT through the reference pieces. `sampler_tiny`: 10 steps; `sampler_tiny_50`: the
     50 flow steps BASELINE config 2 names (textimage2video.py:367-394 with sampling_steps=50), 6 of them kept."""
     print(name)
@@ -142,21 +178,25 @@ def gen_sampler(ns, steps=10, keep=(0, 1, 2, 5, 9), name="sampler_tiny"):
     z = torch.randn(48, 1, 16, 16, generator=g)
     shift, gs = 5.0, 5.0
     keep = list(keep)
-    S = ns.unipc.FlowUniPCMultistepScheduler
     arrs = {}
     for mode in ("t2v", "i2v"):
         i2v = mode == "i2v"
         rec_ref = []
         # composition of the reference pieces exactly as textimage2video.py:329-394 / 521-601 orders them
         with torch.amp.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
-            sch = S(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
-            sch.set_timesteps(steps, device="cpu", shift=shift)
+            if solver == "unipc":                                                  # :335-342
+                sch = ns.unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+                sch.set_timesteps(steps, device="cpu", shift=shift)
+                timesteps = sch.timesteps
+            else:                                                                  # 'dpm++' :343-351
+                sch = ns.dpm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+                timesteps, _ = ns.dpm.retrieve_timesteps(sch, device="cpu", sigmas=ns.dpm.get_sampling_sigmas(steps, shift))
             latent = noise
             _, mask2 = _refimport.ref_masks_like([noise], zero=i2v)
             if i2v:
                 latent = (1. - mask2[0]) * z + mask2[0] * latent
             seq_len = 4 * 8 * 8
-            for t in sch.timesteps:
+            for t in timesteps:
                 timestep = torch.stack([t])
                 temp_ts = (mask2[0][0][:, ::2, ::2] * timestep).flatten()
                 temp_ts = torch.cat([temp_ts, temp_ts.new_ones(seq_len - temp_ts.size(0)) * timestep])
@@ -170,7 +210,8 @@ def gen_sampler(ns, steps=10, keep=(0, 1, 2, 5, 9), name="sampler_tiny"):
                 rec_ref.append((npred, latent))
         rec = []
         with torch.no_grad():
-            mine = sampler.denoise(sd, cfg, noise, [ctx], [ctxn], steps, shift, gs, z=(z if i2v else None), record=rec)
+            mine = sampler.denoise(sd, cfg, noise, [ctx], [ctxn], steps, shift, gs, z=(z if i2v else None), record=rec,
+                                   sample_solver=solver)
         for (a, b), (c_, d) in zip(rec_ref, rec):
             assert torch.equal(a, c_) and torch.equal(b, d), "oracle sampler != reference"
         # per-step tensors kept (ALL steps were checked bit-identical above)
@@ -178,6 +219,7 @@ def gen_sampler(ns, steps=10, keep=(0, 1, 2, 5, 9), name="sampler_tiny"):
         arrs[f"{mode}_latents"] = torch.stack([rec_ref[i][1] for i in keep])
         arrs["kept_steps"] = torch.tensor(keep)
     save(name, seed=0, steps=steps, shift=shift, guide_scale=gs, noise=noise, ctx=ctx, ctx_null=ctxn, z=z, **arrs)
+    return mine
 
 
 def gen_vae(ns):
@@ -348,7 +390,8 @@ def main():
     torch.set_num_threads(8)
     only = sys.argv[1:]
     gens = {"unipc": lambda: gen_unipc(ns), "masks": gen_masks, "text_weight": gen_text_weight, "dit_tiny": lambda: gen_dit_tiny(ns),
-            "sampler": lambda: gen_sampler(ns),
+            "sampler": lambda: gen_sampler(ns), "dpmpp": lambda: gen_dpmpp(ns),
+            "sampler_dpmpp": lambda: gen_sampler(ns, steps=12, keep=(0, 1, 2, 6, 10, 11), name="sampler_tiny_dpmpp", solver="dpm++"),
             "sampler50": lambda: gen_sampler(ns, steps=50, keep=(0, 1, 10, 25, 40, 49), name="sampler_tiny_50"), "vae": lambda: gen_vae(ns), "block": lambda: gen_dit_block_3072(ns),
             "siglip2": gen_siglip2, "projector": gen_projector, "t5": gen_t5}
     for k, fn in gens.items():

@@ -10,7 +10,7 @@ import math
 
 import torch
 
-from . import unipc, wan_dit
+from . import dpmpp, unipc, wan_dit
 
 
 def masks_like(tensors, zero=False):
@@ -58,15 +58,22 @@ def seq_len_of(latent_shape, patch=(1, 2, 2)):
 
 
 def denoise(sd, cfg, noise, context, context_null, steps, shift, guide_scale, z=None, text_weight_cfg=None,
-            record=None):
+            record=None, sample_solver="unipc"):
     """The hot loop of t2v (:356-394) / i2v (:548-601; enabled by passing the first-frame latent z).
 
     text_weight_cfg: None, or dict(total_steps, ratio, w_max, w_min, schedule, bagel_sequence_length)
     which activates UniVid's per-layer context scaling with its forward-call counter.
     record: optional list that receives (noise_pred, latent) per step.
+    sample_solver: 'unipc' (:335-342) or 'dpm++' (:343-351: sigmas from get_sampling_sigmas through retrieve_timesteps).
     """
-    sched = unipc.FlowUniPC(num_train_timesteps=1000, shift=1)
-    timesteps = sched.set_timesteps(steps, shift=shift)
+    if sample_solver == "unipc":
+        sched = unipc.FlowUniPC(num_train_timesteps=1000, shift=1)
+        timesteps = sched.set_timesteps(steps, shift=shift)
+    elif sample_solver == "dpm++":
+        sched = dpmpp.FlowDPMpp(num_train_timesteps=1000, shift=1)
+        timesteps = sched.set_timesteps(sigmas=dpmpp.get_sampling_sigmas(steps, shift))
+    else:
+        raise NotImplementedError("Unsupported solver.")                                # :352-353
     latent = noise
     i2v = z is not None
     _, mask2 = masks_like([noise], zero=i2v)

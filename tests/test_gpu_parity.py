@@ -496,6 +496,43 @@ def test_unipc_and_cfg_kernels_are_bit_exact():
     assert torch.equal(prev, s2.step(ref_np.to(DEV), s2.timesteps[0], x, return_dict=False)[0])
 
 
+def test_dpmpp_kernel_is_bit_exact():
+    """sample_solver='dpm++' (textimage2video.py:343-351): given identical model outputs the HIP DPM-Solver++ trajectory equals
+    the CPU oracle's bit for bit at 10, 20, 2 and 1 steps (first-order warm-up, midpoint second-order steps, the final step onto
+    sigma 0 where lambda is +inf), and the reference's golden trajectory to 2e-6 (another host's log/exp may differ in the
+    last place)."""
+    from oracle import dpmpp as od
+    from univid_amd.wan.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
+    g = load_golden("dpmpp")
+    for steps in (10, 20, 2, 1):
+        s = FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        ts, n = retrieve_timesteps(s, device="cpu", sigmas=get_sampling_sigmas(steps, 5.0))
+        assert n == steps
+        if f"timesteps_{steps}_5.0" in g:
+            assert torch.equal(ts, g[f"timesteps_{steps}_5.0"]) and torch.equal(s.sigmas, g[f"sigmas_{steps}_5.0"])
+        o = od.FlowDPMpp(1000, shift=1)
+        o.set_timesteps(sigmas=od.get_sampling_sigmas(steps, 5.0))
+        lat, lo = g["x"].to(DEV), g["x"]
+        for i, t in enumerate(ts):
+            lat = s.step(g[f"model_outputs_{steps}"][i].to(DEV), t, lat, return_dict=False)[0]
+            lo = o.step(g[f"model_outputs_{steps}"][i], t, lo)
+            assert torch.equal(lat.cpu(), lo), f"DPM++ {steps} steps, step {i}: HIP update differs from the oracle"
+            assert torch.allclose(lat.cpu(), g[f"trajectory_{steps}"][i], rtol=2e-6, atol=2e-6), f"DPM++ step {i} vs reference golden"
+    # fused CFG + convert path == separate path
+    s1 = FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1)
+    s1.set_timesteps(sigmas=get_sampling_sigmas(10, 5.0), device="cpu")
+    mo = g["model_outputs_10"]
+    c, u, x = mo[0].to(DEV), mo[1].to(DEV), g["x"].to(DEV)
+    prev, npred = s1.step_cfg(c, u, 5.0, s1.timesteps[0], x, want_noise_pred=True)
+    ref_np = mo[1] + 5.0 * (mo[0] - mo[1])
+    assert torch.equal(npred.cpu(), ref_np)
+    s2 = FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1)
+    s2.set_timesteps(sigmas=get_sampling_sigmas(10, 5.0), device="cpu")
+    assert torch.equal(prev, s2.step(ref_np.to(DEV), s2.timesteps[0], x, return_dict=False)[0])
+    with pytest.raises(NotImplementedError):
+        FlowDPMSolverMultistepScheduler(solver_type="heun")
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # DiT
 # ---------------------------------------------------------------------------------------------------------------
@@ -847,6 +884,40 @@ def test_sampler_trajectories_vs_golden():
             assert v < SAMPLER10_GATE(k), f"{mode} {k}: rel rms {v:.3e}"
         if mode == "i2v":
             assert torch.equal(final[:, 0].cpu(), g["z"][:, 0]), "i2v must keep the first latent frame pinned to z"
+
+
+def test_sampler_dpmpp_trajectories_vs_golden():
+    """The reference's other solver (sample_solver='dpm++', textimage2video.py:343-351, 535-543): 12 DPM-Solver++ steps of the
+    tiny DiT, t2v and i2v, against the fixture generated from the reference's FlowDPMSolverMultistepScheduler; also through
+    WanTI2V.t2v(sample_solver=...) and the unsupported-solver error."""
+    from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+    g = load_golden("sampler_tiny_dpmpp")
+    cfg, sd, m = _tiny_model(g["seed"])
+    pipe = WanTI2V(TI2VConfig, model=m, device=DEV)
+    keep = g["kept_steps"].tolist()
+    for mode in ("t2v", "i2v"):
+        rec = []
+        with torch.no_grad():
+            final = pipe.denoise(g["noise"].to(DEV), [g["ctx"].to(DEV)], [g["ctx_null"].to(DEV)], g["steps"], g["shift"],
+                                 g["guide_scale"], z=(g["z"].to(DEV) if mode == "i2v" else None), record=rec, sample_solver="dpm++")
+        assert len(rec) == g["steps"] and torch.equal(final, rec[-1][1]) and torch.isfinite(final).all()
+        meas = {}
+        for j, i in enumerate(keep):
+            meas[f"noise_pred_step{i}"] = _rel_rms(rec[i][0], g[f"{mode}_noise_pred"][j])
+            meas[f"latent_step{i}"] = _rel_rms(rec[i][1], g[f"{mode}_latents"][j])
+        record_margin(f"12-step DPM-Solver++ {mode} trajectory (tiny DiT) rel rms vs reference", **meas)
+        for k, v in meas.items():
+            assert v < SAMPLER10_GATE(k), f"{mode} {k}: rel rms {v:.3e}"
+        if mode == "i2v":
+            assert torch.equal(final[:, 0].cpu(), g["z"][:, 0])
+    with torch.no_grad():
+        lat = pipe.t2v("", size=(256, 256), frame_num=13, shift=g["shift"], sample_solver="dpm++", sampling_steps=g["steps"],
+                       guide_scale=g["guide_scale"], prompt_embeds=[g["ctx"]], negative_prompt_embeds=[g["ctx_null"]],
+                       noise=g["noise"].to(DEV), decode=False)
+    assert torch.equal(lat, pipe.denoise(g["noise"].to(DEV), [g["ctx"].to(DEV)], [g["ctx_null"].to(DEV)], g["steps"], g["shift"],
+                                         g["guide_scale"], sample_solver="dpm++"))
+    with pytest.raises(NotImplementedError):
+        pipe.denoise(g["noise"].to(DEV), [g["ctx"].to(DEV)], [g["ctx_null"].to(DEV)], 2, 5.0, 5.0, sample_solver="ddim")
 
 
 def _rel_rms(a, b):

@@ -9,7 +9,7 @@ import os
 import pytest
 import torch
 
-from oracle import sampler, unipc, wan_dit, wan_vae
+from oracle import dpmpp, sampler, unipc, wan_dit, wan_vae
 
 from conftest import GOLDEN, load_golden
 
@@ -30,6 +30,28 @@ def test_unipc_schedule_and_trajectory():
     for i, t in enumerate(s.timesteps):
         lat = s.step(g["model_outputs"][i], t, lat)
         assert torch.equal(lat, g["trajectory"][i]), f"step {i}"
+
+
+def test_dpmpp_schedule_and_trajectory():
+    """sample_solver='dpm++' (textimage2video.py:343-351): sigmas / timesteps through get_sampling_sigmas + retrieve_timesteps
+    and full trajectories at 10 and 20 steps (the < 15-step rule of fm_solvers.py:771-777 is moot at order 2, both are
+    pinned), and the 2- and 1-step corner cases, against the imported reference's outputs."""
+    g = load_golden("dpmpp")
+    for steps, shift in ((50, 5.0), (10, 5.0), (20, 3.0), (2, 5.0), (1, 5.0)):
+        s = dpmpp.FlowDPMpp(1000, shift=1)
+        ts = s.set_timesteps(sigmas=dpmpp.get_sampling_sigmas(steps, shift))
+        assert torch.equal(ts, g[f"timesteps_{steps}_{shift}"])
+        assert torch.equal(s.sigmas, g[f"sigmas_{steps}_{shift}"])
+    assert g["timesteps_50_5.0"][0].item() == 1000 and g["sigmas_50_5.0"][-1].item() == 0.0
+    for steps in (10, 20, 2, 1):
+        s = dpmpp.FlowDPMpp(1000, shift=1)
+        s.set_timesteps(sigmas=dpmpp.get_sampling_sigmas(steps, 5.0))
+        lat = g["x"]
+        for i, t in enumerate(s.timesteps):
+            lat = s.step(g[f"model_outputs_{steps}"][i], t, lat)
+            assert torch.equal(lat, g[f"trajectory_{steps}"][i]), f"{steps} steps, step {i}"
+        # final sigma 0: the last update returns the last x0 prediction itself (lambda_t = +inf, exp(-h) = 0)
+        assert torch.isfinite(lat).all()
 
 
 def test_masks_like():
@@ -81,7 +103,7 @@ def test_dit_block_ti2v5b_width():
         assert torch.equal(out, g["out_" + name])
 
 
-@pytest.mark.parametrize("fixture", ["sampler_tiny", "sampler_tiny_50"])
+@pytest.mark.parametrize("fixture", ["sampler_tiny", "sampler_tiny_50", "sampler_tiny_dpmpp"])
 def test_sampler_trajectories(fixture):
     """10-step and 50-step (BASELINE config 2's step count) t2v / i2v trajectories: the oracle loop reproduces the reference
     pieces' latents bit for bit at every kept step."""
@@ -89,11 +111,12 @@ def test_sampler_trajectories(fixture):
     cfg = wan_dit.TINY_CFG
     sd = wan_dit.make_state_dict(cfg, g["seed"])
     keep = g["kept_steps"].tolist()
+    solver = "dpm++" if fixture.endswith("dpmpp") else "unipc"
     for mode in ("t2v", "i2v"):
         rec = []
         with torch.no_grad():
             sampler.denoise(sd, cfg, g["noise"], [g["ctx"]], [g["ctx_null"]], g["steps"], g["shift"], g["guide_scale"],
-                            z=(g["z"] if mode == "i2v" else None), record=rec)
+                            z=(g["z"] if mode == "i2v" else None), record=rec, sample_solver=solver)
         for j, i in enumerate(keep):
             assert torch.equal(rec[i][0], g[f"{mode}_noise_pred"][j]), f"{mode} noise_pred step {i}"
             assert torch.equal(rec[i][1], g[f"{mode}_latents"][j]), f"{mode} latent step {i}"

@@ -50,6 +50,7 @@ SIGNATURES = {
     "uv_cfg_convert": [_P, _P, _P, _F, _F, _P, _P, _L, _P],
     "uv_unipc_corrector": [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _L, _P],
     "uv_unipc_predictor": [_P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _P],
+    "uv_dpmpp_update": [_P, _P, _P, _P, _F, _F, _F, _I, _L, _P],
     "uv_conv3d_f32": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                       _P, _L, _P],
     "uv_conv3d_bf16x3": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,

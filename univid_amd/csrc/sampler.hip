@@ -9,6 +9,8 @@
 //   convert_model_output (x0 = x - sigma*v)         models/wan/utils/fm_solvers_unipc.py:317-333
 //   multistep_uni_c_bh_update (corrector)           models/wan/utils/fm_solvers_unipc.py:545-628
 //   multistep_uni_p_bh_update (predictor)           models/wan/utils/fm_solvers_unipc.py:397-486
+//   dpm_solver_first_order_update / multistep_dpm_solver_second_order_update (dpmsolver++, midpoint)
+//                                                   models/wan/utils/fm_solvers.py:417-485, 488-595
 #include "common.h"
 
 // noise_pred = u + gs*(c - u);  x0 = sample - sigma * noise_pred
@@ -85,5 +87,33 @@ extern "C" int uv_unipc_predictor(const float* x, const float* m0, const float* 
     hipLaunchKernelGGL(unipc_predictor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, m0, m_prev, out, r,
                        c1, c2, rk, order, n);
     UV_CHECK_LAUNCH("uv_unipc_predictor");
+    return 0;
+}
+
+// DPM-Solver++ (sample_solver='dpm++'), coefficients r = sigma_t/sigma_s0, c = alpha_t*(exp(-h)-1), inv_r0 = 1/r0 from the host:
+// order 1: out = r*x - c*m0
+// order 2: out = (r*x - c*m0) - (0.5*c) * (inv_r0 * (m0 - m1))          (midpoint; 0.5*c is exact in fp32)
+__global__ void dpmpp_update_kernel(const float* x, const float* m0, const float* m1, float* out, float r, float c,
+                                    float inv_r0, int order, long n) {
+    const float ch = __fmul_rn(0.5f, c);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float m = m0[i];
+        float v = __fsub_rn(__fmul_rn(r, x[i]), __fmul_rn(c, m));
+        if (order == 2) {
+            const float d1 = __fmul_rn(inv_r0, __fsub_rn(m, m1[i]));
+            v = __fsub_rn(v, __fmul_rn(ch, d1));
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int uv_dpmpp_update(const float* x, const float* m0, const float* m1, float* out, float r, float c, float inv_r0,
+                               int order, long n, void* stream) {
+    UV_CHECK_ARG(x && m0 && out && n > 0, "uv_dpmpp_update: bad arguments");
+    UV_CHECK_ARG(order == 1 || (order == 2 && m1), "uv_dpmpp_update: order %d unsupported / history missing", order);
+    const int blocks = (int)min((n + 255) / 256, (long)2048);
+    hipLaunchKernelGGL(dpmpp_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, m0, m1, out, r, c, inv_r0,
+                       order, n);
+    UV_CHECK_LAUNCH("uv_dpmpp_update");
     return 0;
 }

@@ -17,6 +17,7 @@ from typing import Callable, List, Optional
 
 import torch
 
+from .fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
 from .fm_solvers_unipc import FlowUniPCMultistepScheduler
 from .model import WanModel
 
@@ -209,7 +210,8 @@ class WanTI2V:
                         n_prompt=n_prompt, seed=seed, offload_model=offload_model, **kw)
 
     # ---- the hot loop ----------------------------------------------------------------------------------------
-    def denoise(self, noise, context, context_null, sampling_steps, shift, guide_scale, z=None, record=None, graph=None):
+    def denoise(self, noise, context, context_null, sampling_steps, shift, guide_scale, z=None, record=None, graph=None,
+                sample_solver="unipc"):
         """Steps of t2v (:356-394) / i2v (:548-601) on a given noise latent [C, f, h, w] (fp32, on device).
 
         z: first-frame latent [C, 1, h, w] switches on the i2v masking (mask2 zero on frame 0, :550-551, :598).
@@ -219,13 +221,21 @@ class WanTI2V:
             on for small latents, where ~100 launches of a few microseconds each make the step launch-bound; off for large ones
             (kernel time is 99 % of a step at 49 x 704 x 1280) and whenever a hook or a parallel mode owns the forward.
             Results are bit-identical either way (same kernels, same order).
+        sample_solver: 'unipc' (:335-342) or 'dpm++' (:343-351), as in the reference.
         Returns the final latent.
         """
         dev = self.device
-        sched = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
-                                            use_dynamic_shifting=False)
-        sched.set_timesteps(sampling_steps, device="cpu", shift=shift)
-        timesteps = sched.timesteps
+        if sample_solver == "unipc":
+            sched = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
+                                                use_dynamic_shifting=False)
+            sched.set_timesteps(sampling_steps, device="cpu", shift=shift)
+            timesteps = sched.timesteps
+        elif sample_solver == "dpm++":
+            sched = FlowDPMSolverMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
+                                                    use_dynamic_shifting=False)
+            timesteps, _ = retrieve_timesteps(sched, device="cpu", sigmas=get_sampling_sigmas(sampling_steps, shift))
+        else:
+            raise NotImplementedError("Unsupported solver.")
         latent = noise.to(device=dev, dtype=torch.float32).contiguous()
         i2v = z is not None
         _, mask2 = masks_like([latent], zero=i2v)
@@ -307,8 +317,6 @@ class WanTI2V:
             guide_scale=5.0, n_prompt="", seed=-1, offload_model=True, *, prompt_embeds=None, negative_prompt_embeds=None,
             noise=None, decode=True):
         """textimage2video.py:239-411. Returns the video [3, N, H, W] in [-1, 1] (or the latent if decode=False)."""
-        if sample_solver != "unipc":
-            raise NotImplementedError("UniVid hard-codes sample_solver='unipc' (models/model_pipeline.py:2625)")
         F = frame_num
         z_dim = self.model.in_dim
         target_shape = (z_dim, (F - 1) // self.vae_stride[0] + 1, size[1] // self.vae_stride[1],
@@ -320,7 +328,7 @@ class WanTI2V:
         if noise is None:
             noise = self._noise(target_shape, seed)
         with torch.no_grad():
-            x0 = self.denoise(noise, context, context_null, sampling_steps, shift, guide_scale)
+            x0 = self.denoise(noise, context, context_null, sampling_steps, shift, guide_scale, sample_solver=sample_solver)
             if not decode:
                 return x0
             if self.vae is None:
@@ -332,8 +340,6 @@ class WanTI2V:
             negative_prompt_embeds=None, noise=None, decode=True):
         """textimage2video.py:413-619. `img` is a PIL image, or a float tensor [3, H, W] in [-1, 1] that already has
         the output size (the PIL resize/crop of :462-477 is host-side image I/O)."""
-        if sample_solver != "unipc":
-            raise NotImplementedError("UniVid hard-codes sample_solver='unipc' (models/model_pipeline.py:2625)")
         if self.vae is None:
             raise ValueError("i2v needs a VAE (first-frame encode, :512)")
         dh, dw = self.patch_size[1] * self.vae_stride[1], self.patch_size[2] * self.vae_stride[2]
@@ -364,5 +370,5 @@ class WanTI2V:
         context_null = self._encode(n_prompt, negative_prompt_embeds)
         with torch.no_grad():
             z = self.vae.encode([img_t])[0]
-            x0 = self.denoise(noise, context, context_null, sampling_steps, shift, guide_scale, z=z)
+            x0 = self.denoise(noise, context, context_null, sampling_steps, shift, guide_scale, z=z, sample_solver=sample_solver)
             return self.vae.decode([x0])[0] if decode else x0
