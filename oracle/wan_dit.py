@@ -21,6 +21,17 @@ def linear_ac(x, w, b):
     return F.linear(x.to(BF16), w.to(BF16), None if b is None else b.to(BF16))
 
 
+def lin(sd, key, x):
+    """The nn.Linear `key` of the state dict under autocast(bf16). If the dict also holds `key.lora_A.weight` / `key.lora_B.weight`
+    / `key.lora_scaling` (test-only extension: an UN-MERGED PEFT adapter on that layer, oracle/lora.py) the adapter branch is added
+    the way PEFT's lora.Linear does."""
+    if key + ".lora_A.weight" in sd:
+        from . import lora
+        return lora.lora_linear_ac(x, sd[key + ".weight"], sd[key + ".bias"], sd[key + ".lora_A.weight"], sd[key + ".lora_B.weight"],
+                                   float(sd[key + ".lora_scaling"]))
+    return linear_ac(x, sd[key + ".weight"], sd[key + ".bias"])
+
+
 def sinusoidal_embedding_1d(dim, position):
     """model.py:14-24 - fp64 outer product, cos || sin."""
     half = dim // 2
@@ -87,22 +98,22 @@ def self_attention(sd, pre, x, seq_lens, grid_sizes, freqs, num_heads, eps):
     """WanSelfAttention.forward model.py:126-155."""
     b, s = x.shape[:2]
     d = x.shape[2] // num_heads
-    q = rms_norm(linear_ac(x, sd[pre + "q.weight"], sd[pre + "q.bias"]), sd[pre + "norm_q.weight"], eps).view(b, s, num_heads, d)
-    k = rms_norm(linear_ac(x, sd[pre + "k.weight"], sd[pre + "k.bias"]), sd[pre + "norm_k.weight"], eps).view(b, s, num_heads, d)
-    v = linear_ac(x, sd[pre + "v.weight"], sd[pre + "v.bias"]).view(b, s, num_heads, d)
+    q = rms_norm(lin(sd, pre + "q", x), sd[pre + "norm_q.weight"], eps).view(b, s, num_heads, d)
+    k = rms_norm(lin(sd, pre + "k", x), sd[pre + "norm_k.weight"], eps).view(b, s, num_heads, d)
+    v = lin(sd, pre + "v", x).view(b, s, num_heads, d)
     o = attention_core(rope_apply(q, grid_sizes, freqs), rope_apply(k, grid_sizes, freqs), v, k_lens=seq_lens)
-    return linear_ac(o.flatten(2), sd[pre + "o.weight"], sd[pre + "o.bias"])
+    return lin(sd, pre + "o", o.flatten(2))
 
 
 def cross_attention(sd, pre, x, context, num_heads, eps):
     """WanCrossAttention.forward model.py:160-180 (context_lens=None: all text_len rows attended)."""
     b = x.size(0)
     d = x.shape[2] // num_heads
-    q = rms_norm(linear_ac(x, sd[pre + "q.weight"], sd[pre + "q.bias"]), sd[pre + "norm_q.weight"], eps).view(b, -1, num_heads, d)
-    k = rms_norm(linear_ac(context, sd[pre + "k.weight"], sd[pre + "k.bias"]), sd[pre + "norm_k.weight"], eps).view(b, -1, num_heads, d)
-    v = linear_ac(context, sd[pre + "v.weight"], sd[pre + "v.bias"]).view(b, -1, num_heads, d)
+    q = rms_norm(lin(sd, pre + "q", x), sd[pre + "norm_q.weight"], eps).view(b, -1, num_heads, d)
+    k = rms_norm(lin(sd, pre + "k", context), sd[pre + "norm_k.weight"], eps).view(b, -1, num_heads, d)
+    v = lin(sd, pre + "v", context).view(b, -1, num_heads, d)
     o = attention_core(q, k, v)
-    return linear_ac(o.flatten(2), sd[pre + "o.weight"], sd[pre + "o.bias"])
+    return lin(sd, pre + "o", o.flatten(2))
 
 
 def block_forward(sd, pre, x, e0, seq_lens, grid_sizes, freqs, context, num_heads, eps, context_scale=None):
@@ -119,9 +130,9 @@ def block_forward(sd, pre, x, e0, seq_lens, grid_sizes, freqs, context, num_head
     hn = layer_norm(x, eps, sd[pre + "norm3.weight"], sd[pre + "norm3.bias"])               # :251 cross_attn_norm
     x = x + cross_attention(sd, pre + "cross_attn.", hn, ctx, num_heads, eps)
     h = layer_norm(x, eps).float() * (1 + e[4].squeeze(2)) + e[3].squeeze(2)                  # :253
-    y = linear_ac(h, sd[pre + "ffn.0.weight"], sd[pre + "ffn.0.bias"])
+    y = lin(sd, pre + "ffn.0", h)
     y = F.gelu(y, approximate="tanh")
-    y = linear_ac(y, sd[pre + "ffn.2.weight"], sd[pre + "ffn.2.bias"])
+    y = lin(sd, pre + "ffn.2", y)
     return x + y * e[5].squeeze(2)                                                           # :255 fp32
 
 

@@ -548,13 +548,13 @@ def _tiny_model(seed=0, **over):
 
 def _truth_forward(sd, cfg, *args, **kw):
     """The oracle with every bf16 rounding removed (fp32 everywhere): the "truth" both implementations approximate."""
-    from oracle import wan_dit
+    from oracle import lora as ora_lora, wan_dit
     old = wan_dit.BF16
-    wan_dit.BF16 = torch.float32
+    wan_dit.BF16 = ora_lora.BF16 = torch.float32
     try:
         return wan_dit.dit_forward(sd, cfg, *args, **kw)
     finally:
-        wan_dit.BF16 = old
+        wan_dit.BF16 = ora_lora.BF16 = old
 
 
 def test_dit_tiny_forward_vs_golden():
@@ -1287,6 +1287,137 @@ def test_checkpoint_directory_written_independently_loads_and_runs(tmp_path):
     save_file({k: sd[k].contiguous() for k in names[cuts[2]:cuts[3] - 1]}, str(d / "diffusion_pytorch_model-00003-of-00003.safetensors"))
     with pytest.raises(RuntimeError, match="does not match"):
         WanModel.from_pretrained(str(d))
+
+
+def _write_adapter(path, factors, r, alpha, with_adapter_name=False, **cfg_over):
+    """A PEFT adapter directory built by hand (adapter_config.json + adapter_model.safetensors with PEFT's key names), not by
+    anything in univid_amd."""
+    import json
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    cfg = dict(peft_type="LORA", r=r, lora_alpha=alpha, lora_dropout=0.0, bias="none", use_rslora=False, use_dora=False,
+               fan_in_fan_out=False, target_modules=sorted(factors), task_type="FEATURE_EXTRACTION", inference_mode=True)
+    cfg.update(cfg_over)
+    with open(os.path.join(path, "adapter_config.json"), "w") as f:
+        json.dump(cfg, f)
+    mid = ".default" if with_adapter_name else ""
+    t = {}
+    for name, (a, b) in factors.items():
+        t[f"base_model.model.{name}.lora_A{mid}.weight"] = a.contiguous()
+        t[f"base_model.model.{name}.lora_B{mid}.weight"] = b.contiguous()
+    save_file(t, os.path.join(path, "adapter_model.safetensors"))
+
+
+def _lora_factors(cfg, names, r, seed, b_std=0.05):
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"ffn.0": (cfg["ffn_dim"], cfg["dim"]), "ffn.2": (cfg["dim"], cfg["ffn_dim"])}
+    out = {}
+    for n in names:
+        o, i = next((v for k, v in shapes.items() if n.endswith(k)), (cfg["dim"], cfg["dim"]))
+        # lora_A ~ kaiming-uniform-like, lora_B as after training (PEFT starts it at zero): large enough that the adapter
+        # moves the output far beyond the bf16 noise floor
+        out[n] = (torch.randn(r, i, generator=g) / math.sqrt(i), torch.randn(o, r, generator=g) * b_std)
+    return out
+
+
+def _sd_with_adapter(sd, factors, scaling):
+    sd = dict(sd)
+    for n, (a, b) in factors.items():
+        sd[n + ".lora_A.weight"], sd[n + ".lora_B.weight"], sd[n + ".lora_scaling"] = a, b, scaling
+    return sd
+
+
+def test_lora_adapter_directory_tiny_model_vs_unmerged_oracle(tmp_path):
+    """inference.py --use_lora (reference inference.py:198-264 -> LoRAManager.load_lora_weights, model_pipeline.py:724-750): a PEFT
+    adapter directory written by hand is loaded through `pipeline.lora_manager.load_lora_weights(dir, pipeline.dit_model)`, the HIP
+    forward with the adapter folded in is compared with the oracle running the adapter UN-MERGED (PEFT's lora.Linear arithmetic
+    restated in oracle/lora.py), and unloading restores the base model bit for bit."""
+    from oracle import wan_dit
+    from univid_amd.model_pipeline import CrossAttentionConfig, CrossAttentionFusionPipeline
+    from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+    g = load_golden("dit_tiny")
+    cfg, sd, m = _tiny_model(g["seed"])
+    names = [f"blocks.{i}.{a}.{p}" for i in range(2) for a in ("cross_attn", "self_attn") for p in "qkvo"] + ["blocks.1.ffn.0", "blocks.0.ffn.2"]
+    r, alpha = 8, 16
+    factors = _lora_factors(cfg, names, r, 3, b_std=0.2)
+    _write_adapter(str(tmp_path / "best"), factors, r, alpha, with_adapter_name=True)
+    pipe = CrossAttentionFusionPipeline(CrossAttentionConfig(use_lora=True), wan_pipeline=WanTI2V(TI2VConfig, model=m, device=DEV))
+    Lt = 256
+    args = ([g["x"].to(DEV)], g["t_one"].to(DEV), [g["ctx"].to(DEV)], Lt)
+    with torch.no_grad():
+        base = pipe.dit_model(*args)[0]
+        pipe.lora_manager.load_lora_weights(str(tmp_path / "best"), pipe.dit_model)
+        got = pipe.dit_model(*args)[0]
+        sd_l = _sd_with_adapter(sd, factors, alpha / r)
+        ref = wan_dit.dit_forward(sd_l, cfg, [g["x"]], g["t_one"], [g["ctx"]], Lt)[0]
+        truth = _truth_forward(sd_l, cfg, [g["x"]], g["t_one"], [g["ctx"]], Lt)[0]
+    effect = _rel_rms(ref, g["out_one"])
+    assert effect > 0.05, f"the test adapter must move the output well above the bf16 noise floor (moved it by {effect:.3f})"
+    # Merged and un-merged projections round differently (one bf16 rounding of W + dW against separate roundings of the two
+    # branches), and this adapter is deliberately large: measured 63 % inside, max 1.2e-3 of the range - and the merged HIP result
+    # is as close to the unrounded truth as PEFT's un-merged arithmetic is (rms ratio 0.985), which is the gate that matters.
+    assert_model_close(got, ref, truth, frac=0.45, max_rel=1.9e-3, truth_ratio=1.05, name="tiny DiT + LoRA (merged on HIP vs un-merged oracle)")
+    # the adapter's EFFECT is reproduced, not just the base model: (adapted - base) on HIP vs on the oracle
+    d_hip, d_ref = (got - base).cpu(), ref - g["out_one"]
+    rel = float((d_hip - d_ref).pow(2).mean().sqrt() / d_ref.pow(2).mean().sqrt())
+    record_margin("tiny DiT + LoRA: error of the adapter's effect (rel rms)", effect_rel_rms=rel, effect_size=effect)
+    assert rel < 1.2e-2, f"adapter effect off by {rel:.3e}"          # measured 7.6e-3 for an effect of 15 % of the output
+    st = pipe.lora_manager.get_statistics()
+    assert st["lora_modules"] == len(names) and st["module_breakdown"]["cross_attention"] == 8 and st["lora_config"]["rank"] == r
+    with pytest.raises(RuntimeError):
+        pipe.lora_manager.load_lora_weights(str(tmp_path / "best"), pipe.dit_model)       # already merged
+    with torch.no_grad():
+        pipe.lora_manager.unload()
+        assert torch.equal(pipe.dit_model(*args)[0], base), "unload() must restore the base model bit for bit"
+
+
+def test_lora_adapter_ti2v5b_width_block_vs_unmerged_oracle(tmp_path):
+    """The same at the production width: one TI2V-5B block (L = 1014) with a rank-16 adapter on the cross- and self-attention
+    projections and ffn.0 ('smart_wan_dit'-style targets, model_pipeline.py:501-506), merged on HIP vs un-merged in the oracle."""
+    from oracle import wan_dit
+    from univid_amd.lora import LoRAManager
+    from univid_amd.wan.model import WanAttentionBlock, _freqs_device, rope_params
+    cfg = wan_dit.TI2V_5B_CFG
+    dim, heads = cfg["dim"], cfg["num_heads"]
+    sd = wan_dit.make_state_dict(dict(cfg, num_layers=1), 11)
+    sd = {k: v for k, v in sd.items() if k.startswith("blocks.0.")}
+    names = [f"blocks.0.{a}.{p}" for a in ("cross_attn", "self_attn") for p in "qkvo"] + ["blocks.0.ffn.0"]
+    r, alpha = 16, 32
+    factors = _lora_factors(cfg, names, r, 4)
+    _write_adapter(str(tmp_path / "ad"), factors, r, alpha)
+    gen = torch.Generator().manual_seed(23)
+    Lt, grid = 1014, (3, 13, 26)
+    x = torch.randn(1, Lt, dim, generator=gen)
+    e_rows = torch.randn(2, 6, dim, generator=gen) * 0.3
+    tid = (torch.arange(Lt) >= 338).long()
+    ctx = (torch.randn(1, 512, dim, generator=gen) * 0.5).to(BF16)
+    e0 = e_rows[tid].unsqueeze(0)
+    freqs = wan_dit.rope_table(dim // heads)
+    sd_l = _sd_with_adapter(sd, factors, alpha / r)
+    from oracle import lora as ora_lora
+    with torch.no_grad():
+        ref = wan_dit.block_forward(sd_l, "blocks.0.", x, e0, torch.tensor([Lt]), torch.tensor([grid]), freqs, ctx, heads, 1e-6)
+        ref_base = wan_dit.block_forward(sd, "blocks.0.", x, e0, torch.tensor([Lt]), torch.tensor([grid]), freqs, ctx, heads, 1e-6)
+        wan_dit.BF16 = ora_lora.BF16 = torch.float32          # the unrounded truth of the adapted block
+        try:
+            truth = wan_dit.block_forward(sd_l, "blocks.0.", x, e0, torch.tensor([Lt]), torch.tensor([grid]), freqs, ctx, heads, 1e-6)
+        finally:
+            wan_dit.BF16 = ora_lora.BF16 = BF16
+    holder = torch.nn.Module()
+    holder.blocks = torch.nn.ModuleList([WanAttentionBlock(dim, cfg["ffn_dim"], heads, cross_attn_norm=True, eps=1e-6)])
+    holder.load_state_dict(sd)
+    holder = holder.to(DEV).eval()
+    LoRAManager().load_lora_weights(str(tmp_path / "ad"), holder)
+    blk = holder.blocks[0]
+    xs = x[0].to(DEV).contiguous()
+    with torch.no_grad():
+        blk.prepare()
+        blk._run(xs, Lt, e_rows.reshape(2, -1).to(DEV), tid.to(torch.int32).to(DEV), grid, _freqs_device(freqs, torch.device(DEV)),
+                 ctx[0].to(DEV), first_block=False)
+    effect = _rel_rms(ref[0] - x[0], ref_base[0] - x[0])
+    assert effect > 0.05, f"adapter effect on the block's update only {effect:.3f}"
+    # measured: 60 % inside, max 2.7e-3 of the range (the un-adapted block: 84.7 %, 1.7e-3)
+    assert_model_close(xs, ref[0], truth[0], frac=0.40, max_rel=4e-3, truth_ratio=1.05, name="TI2V-5B block + LoRA r16 (merged on HIP vs un-merged oracle)")
 
 
 def test_model_errors_are_loud():

@@ -307,3 +307,56 @@ def test_bench_bare_multi_gpu_invocation_starts_one_rank_per_gpu():
     env2.pop("UV_BENCH_DRYRUN", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in (r.stderr + r.stdout)
+
+
+def test_lora_adapter_directory_is_parsed_merged_and_unloaded(tmp_path):
+    """univid_amd.lora on the host: PEFT key formats (with / without the adapter name, safetensors / .bin / the reference's manual
+    lora_weights.pt), scaling rules, merged weight == peft's get_delta_weight arithmetic (oracle/lora.py), bit-exact unload, loud errors."""
+    import json
+    from safetensors.torch import save_file
+    from oracle import lora as ora, wan_dit
+    from univid_amd import lora
+    cfg = dict(wan_dit.TINY_CFG)
+    m = WanModel.from_config(dict(cfg, model_type="ti2v"))
+    m.load_state_dict(wan_dit.make_state_dict(cfg, 0))
+    g = torch.Generator().manual_seed(0)
+    r = 4
+    tgt = {"blocks.0.cross_attn.q": (256, 256), "blocks.1.self_attn.o": (256, 256), "blocks.1.ffn.0": (512, 256)}
+    fac = {n: (torch.randn(r, i, generator=g), torch.randn(o, r, generator=g)) for n, (o, i) in tgt.items()}
+    base = {n: dict(m.named_modules())[n].weight.detach().clone() for n in tgt}
+
+    def write(d, mid, fmt, **over):
+        d.mkdir()
+        (d / "adapter_config.json").write_text(json.dumps({**dict(r=r, lora_alpha=8, use_rslora=False, use_dora=False, bias="none"), **over}))
+        t = {}
+        for n, (a, b) in fac.items():
+            t[f"base_model.model.{n}.lora_A{mid}.weight"], t[f"base_model.model.{n}.lora_B{mid}.weight"] = a, b
+        if fmt == "safetensors":
+            save_file(t, str(d / "adapter_model.safetensors"))
+        else:
+            torch.save(t, str(d / fmt))
+        return str(d)
+
+    for i, (mid, fmt, over, scale) in enumerate([("", "safetensors", {}, 2.0), (".default", "adapter_model.bin", {}, 2.0),
+                                                  (".default", "lora_weights.pt", {"use_rslora": True}, 4.0)]):
+        mgr = lora.LoRAManager()
+        assert mgr.load_lora_weights(write(tmp_path / f"a{i}", mid, fmt, **over), m) is m
+        assert m._prep is None, "merging must drop the prepared bf16 operands"
+        for n, (a, b) in fac.items():
+            assert torch.equal(dict(m.named_modules())[n].weight, ora.merged_weight(base[n], a, b, scale)), (fmt, n)
+        assert mgr.get_statistics()["lora_modules"] == 3
+        mgr.unload()
+        for n in tgt:
+            assert torch.equal(dict(m.named_modules())[n].weight, base[n]), "unload() restores the base weights bit for bit"
+    with pytest.raises(NotImplementedError):
+        lora.LoRAManager().load_lora_weights(write(tmp_path / "dora", "", "safetensors", use_dora=True), m)
+    with pytest.raises(FileNotFoundError):
+        lora.LoRAManager().load_lora_weights(str(tmp_path / "missing"), m)
+    with pytest.raises(NotImplementedError):
+        lora.LoRAManager().apply_lora_to_dit(m)
+    with pytest.raises(KeyError):
+        lora.merge_adapter_(m, {"blocks.0.norm3": fac["blocks.0.cross_attn.q"]}, dict(r=r, lora_alpha=8))
+    with pytest.raises(ValueError):
+        lora.adapter_factors({"base_model.model.blocks.0.cross_attn.q.lora_A.weight": fac["blocks.0.cross_attn.q"][0]})
+    for n in tgt:
+        assert torch.equal(dict(m.named_modules())[n].weight, base[n]), "failed loads must leave the model untouched"

@@ -8,7 +8,8 @@ Mirrors the parts of /root/reference/models/model_pipeline.py that sit directly 
                                              frames=, size=, shift=, seed=) -> (video | None, path | None) (:2577-2655)
 so that inference.py can drive this package unchanged. Everything off the hot path is pluggable instead of
 re-built (SURVEY.md section 2 marks it out of scope): the BAGEL-7B semantic extractor, the ContextProjector adapter,
-the umT5 text encoder, LoRA, training and video file I/O are callables/objects the caller supplies.
+the umT5 text encoder, training and video file I/O are callables/objects the caller supplies. LoRA adapters are loaded
+for inference by `univid_amd.lora.LoRAManager` (merged into the dense weights).
 
 Behaviour kept on purpose: the text-encoder override of the reference is dead code (Python resolves
 `obj(...)` through the type), so the DiT receives the text encoder's embeddings; the per-layer forward hook IS live
@@ -25,6 +26,7 @@ from typing import Callable, List, Optional, Tuple
 
 import torch
 
+from .lora import LoRAManager
 from .wan.textimage2video import TI2VConfig, WanTI2V
 
 
@@ -257,7 +259,8 @@ class CrossAttentionFusionPipeline:
         self.wan_pipeline = wan_pipeline
         self.bagel_extractor = bagel_extractor
         self.context_projector = context_projector
-        self.lora_manager = None
+        # model_pipeline.py:2117: inference.py:218-224 calls `pipeline.lora_manager.load_lora_weights(path, pipeline.dit_model)`
+        self.lora_manager = LoRAManager(config, self.logger) if getattr(config, "use_lora", False) else None
         self.dit_model = wan_pipeline.model
         self.vae_model = wan_pipeline.vae
         self.wan_wrapper = Wan22ContextWrapper(wan_pipeline, context_projector, self.logger, config)

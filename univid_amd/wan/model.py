@@ -55,8 +55,9 @@ class _Prepared:
             # dense weight per projection, so the deltas have to be folded in first.
             raise NotImplementedError(
                 "a LoRA-wrapped nn.Linear (PEFT lora.Linear) was found in the DiT: the HIP path reads dense weights and would "
-                "ignore the adapter. Fold the adapters in with `peft_model.merge_and_unload()` (or LoRAManager's merge), then "
-                "call `WanModel.invalidate()` before the next forward.")
+                "ignore the adapter. Load the adapter directory with `univid_amd.lora.LoRAManager().load_lora_weights(dir, model)` "
+                "(folds it into the dense weights), or fold it in with `peft_model.merge_and_unload()` and call "
+                "`WanModel.invalidate()` before the next forward.")
         w = lin.weight.detach()
         if pad_k and w.shape[1] % pad_k:
             w = torch.nn.functional.pad(w, (0, pad_k - w.shape[1] % pad_k))
