@@ -1470,6 +1470,30 @@ def test_vae_list_api_and_state_is_reset_between_calls():
     assert_f32_close(e[0], g["enc_out_0"])
 
 
+def test_vae_pass_length_does_not_change_the_result():
+    """Decoder passes of several latent frames / encoder passes of several 4-frame chunks (WanVAE_.frames_per_pass) against the
+    reference's one-at-a-time streaming (vae2_2.py:797-806, 824-835): every layer is time-causal with a 2-frame cache, so the values
+    must be IDENTICAL bit for bit - including pass lengths that do not divide the clip, both precisions, and a second clip through the
+    same object (caches cleared, shared scratch reused)."""
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    g = torch.Generator().manual_seed(12)
+    z = torch.randn(48, 6, 2, 3, generator=g)                    # 6 latent frames -> 21 output frames
+    vid = torch.tanh(torch.randn(3, 21, 32, 48, generator=g))    # 1 + 5 chunks of 4 frames
+    z2 = torch.randn(48, 3, 3, 2, generator=g)
+    for prec in ("fp32", "bf16x3"):
+        ref = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=3, precision=prec, frames_per_pass=1)
+        with torch.no_grad():
+            d1, e1, d1b = ref.decode([z.to(DEV)])[0], ref.encode([vid.to(DEV)])[0], ref.decode([z2.to(DEV)])[0]
+        assert d1.shape == (3, 21, 32, 48) and e1.shape == (48, 6, 2, 3)
+        for G in (2, 3, 4, 16):
+            vae = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=3, precision=prec, frames_per_pass=G)
+            with torch.no_grad():
+                d, e, db = vae.decode([z.to(DEV)])[0], vae.encode([vid.to(DEV)])[0], vae.decode([z2.to(DEV)])[0]
+            assert torch.equal(d, d1), f"{prec}: decode with {G} latent frames per pass differs from streaming"
+            assert torch.equal(e, e1), f"{prec}: encode with {G} chunks per pass differs from streaming"
+            assert torch.equal(db, d1b), f"{prec}: second clip (other shape) through the same object, G={G}"
+
+
 def test_vae_bf16x3_precision_mode():
     """Opt-in split-bf16 (3-pass MFMA) convolutions: same function within the north star's rtol 1e-3 / atol 1e-4 on every
     element against the fp32 reference output (measured ~5e-5 max), results differ from the exact-fp32 mode."""

@@ -7,9 +7,10 @@ Encoder3d :500-613, Decoder3d :616-723, WanVAE_ :734-860, Wan2_2_VAE :888-1051.
 
 The nn.Modules below only HOLD parameters (same names and shapes as the reference, so `Wan2.2_VAE.pth` loads);
 all arithmetic runs in `_Engine`, which walks the tree and launches HIP kernels on channels-last fp32 activations
-[T, H, W, C]. The reference's chunked streaming is kept exactly (encode: 1 + 4 + 4 ... frames, decode: one latent
-frame per chunk) because the first-chunk special cases ("Rep", DupUp3D(first_chunk)) are part of the function being
-computed; the per-convolution feature cache (CACHE_T = 2) becomes a 2-frame prefix of each convolution's input ring.
+[T, H, W, C]. The reference's chunked streaming is kept (the first chunk - one frame - on its own, because its special cases
+("Rep", DupUp3D(first_chunk)) are part of the function being computed; then passes of `frames_per_pass` latent frames / 4-frame
+chunks instead of one: same values, larger launches); the per-convolution feature cache (CACHE_T = 2 frames) is a 2-frame tensor
+per convolution that is prepended to each pass's input.
 Everything is fp32 like the reference (`dtype=torch.float`, vae2_2.py:897, 1028, 1042). No eager fallback.
 """
 import logging
@@ -168,7 +169,8 @@ class _ConvOp:
         self.w2d = w.reshape(self.cout, self.cin).contiguous() if (self.kt, self.kh, self.kw) == (1, 1, 1) else None
         self.b = conv.bias.detach().float().contiguous()
         self.w_split = None
-        self.rings = {}
+        self.caches = {}     # (H, W, prefix) -> the cached frames [prefix, H, W, cin_pad] (zeros = the causal zero padding)
+        self.rings = {}      # private input rings of the few convolutions whose channel count is padded (see _Engine.conv_input)
 
     def split(self):
         """bf16 hi/lo planes of the weights for the bf16x3 kernel ([Cout][K/32][32 hi | 32 lo])."""
@@ -177,19 +179,12 @@ class _ConvOp:
             _lib.call("uv_split_weights_bf16x3", _lib.ptr(self.w), _lib.ptr(self.w_split), self.w.numel(), _lib.stream_ptr())
         return self.w_split
 
-    def ring(self, H, W, tmax, prefix=CACHE_T):
-        key = (H, W, tmax, prefix)
-        r = self.rings.get(key)
-        if r is None:
-            r = torch.zeros(prefix + tmax, H, W, self.cin_pad, dtype=torch.float32, device=self.w.device)
-            self.rings[key] = r
-        return r
-
-
-def _shift(ring, T, prefix=CACHE_T):
-    """cache <- last `prefix` frames of [cache | current T frames] (vae2_2.py:219-232 feature-cache update)."""
-    tail = ring[T:T + prefix]
-    ring[:prefix].copy_(tail.clone() if T < prefix else tail)
+    def cache(self, H, W, prefix=CACHE_T):
+        key = (H, W, prefix)
+        c = self.caches.get(key)
+        if c is None:
+            c = self.caches[key] = torch.zeros(prefix, H, W, self.cin_pad, dtype=torch.float32, device=self.w.device)
+        return c
 
 
 class _Engine:
@@ -205,12 +200,46 @@ class _Engine:
             elif isinstance(mod, nn.Conv2d):
                 self.ops[mod] = _ConvOp(mod, is2d=True)
         self.dev = next(model.parameters()).device
+        self.scratch = {}    # (H, W, channels) -> shared conv-input buffer [frames, H, W, channels]
 
     def reset(self):
         """WanVAE_.clear_cache (vae2_2.py:853-860): all cached frames back to the causal zero padding."""
         for op in self.ops.values():
+            for c in op.caches.values():
+                c.zero_()
             for r in op.rings.values():
                 r.zero_()
+
+    def conv_input(self, op, H, W, T, fill, prefix=CACHE_T):
+        """The input of a cached (time-causal) convolution: [cached frames (prefix) | the T current frames, written by fill(dst)]
+        as one [prefix + T, H, W, cin_pad] tensor, with the cache advanced to the last `prefix` frames of it for the next pass
+        (the feature-cache update of vae2_2.py:219-232). The reference keeps 2 frames per convolution; so does this: the
+        [prefix + T]-frame tensor itself is a scratch buffer SHARED by all convolutions of one (H, W, channels) shape, so its size
+        follows the pass length T without multiplying by the number of convolutions. Convolutions whose channel count is padded
+        (the first convolution of encoder and decoder) keep a small private ring instead: their pad channels must stay zero.
+        Returns (input tensor, None | callable to run after the convolution has been launched)."""
+        need = prefix + T
+        if op.cin != op.cin_pad:
+            key = (H, W, prefix)
+            ring = op.rings.get(key)
+            if ring is None or ring.shape[0] < need:
+                grown = torch.zeros(need, H, W, op.cin_pad, dtype=torch.float32, device=self.dev)
+                if ring is not None:
+                    grown[:prefix].copy_(ring[:prefix])
+                ring = op.rings[key] = grown
+            fill(ring[prefix:need])
+            nxt = ring[T:need].clone()
+            return ring[:need], lambda: ring[:prefix].copy_(nxt)
+        key = (H, W, op.cin_pad)
+        ring = self.scratch.get(key)
+        if ring is None or ring.shape[0] < need:
+            self.scratch[key] = None         # release the smaller buffer before allocating the larger one
+            ring = self.scratch[key] = torch.empty(need, H, W, op.cin_pad, dtype=torch.float32, device=self.dev)
+        cache = op.cache(H, W, prefix)
+        ring[:prefix].copy_(cache)
+        fill(ring[prefix:need])
+        cache.copy_(ring[T:need])
+        return ring[:need], None
 
     # -- kernels --
     def _conv(self, op, src, Tin, Hin, Win, Tout, Hout, Wout, st=1, sh=1, sw=1, t_off=0, ph=0, pw=0, up=0, interleave=0,
@@ -245,25 +274,24 @@ class _Engine:
         return out
 
     # -- blocks --
-    def causal_conv(self, conv, x_into_ring, T, H, W, tmax, resid=None, in_split=False):
-        """3x3x3 causal conv over the ring [cache(2) | T frames]; `x_into_ring(dst)` fills the current frames.
+    def causal_conv(self, conv, fill, T, H, W, resid=None, in_split=False):
+        """3x3x3 causal conv over [cache(2) | T frames]; `fill(dst)` writes the current frames.
         in_split: the filler writes split-bf16 activations (bf16x3 mode; zeros stay zeros, so the cache logic is unchanged)."""
         op = self.ops[conv]
-        ring = op.ring(H, W, tmax)
-        x_into_ring(ring[CACHE_T:CACHE_T + T])
+        ring, after = self.conv_input(op, H, W, T, fill)
         y = self._conv(op, ring, CACHE_T + T, H, W, T, H, W, t_off=0, ph=1, pw=1, resid=resid, in_split=in_split)
-        _shift(ring, T)
+        if after is not None:
+            after()
         return y
 
-    def resblock(self, blk, x, tmax):
+    def resblock(self, blk, x):
         """ResidualBlock.forward vae2_2.py:214-235."""
         T, H, W, C = x.shape
         res = blk.residual
         h = x if isinstance(blk.shortcut, nn.Identity) else self._pointwise(self.ops[blk.shortcut], x)
         sp = self.precision == "bf16x3" and C % 32 == 0 and blk.out_dim % 32 == 0
-        y = self.causal_conv(res[2], lambda dst: self._rms_silu(x, res[0].gamma, dst, split=sp), T, H, W, tmax, in_split=sp)
-        return self.causal_conv(res[6], lambda dst: self._rms_silu(y, res[3].gamma, dst, split=sp), T, H, W, tmax, resid=h,
-                                in_split=sp)
+        y = self.causal_conv(res[2], lambda dst: self._rms_silu(x, res[0].gamma, dst, split=sp), T, H, W, in_split=sp)
+        return self.causal_conv(res[6], lambda dst: self._rms_silu(y, res[3].gamma, dst, split=sp), T, H, W, resid=h, in_split=sp)
 
     def attention(self, blk, x):
         """AttentionBlock.forward vae2_2.py:255-277: per-frame single-head attention, head_dim = C, fp32."""
@@ -293,38 +321,38 @@ class _Engine:
                       _lib.ptr(xt), C, sp())
         return out
 
-    def upsample(self, rs, x, first_chunk, tmax):
+    def upsample(self, rs, x, first_chunk):
         """Resample.forward (upsample2d / upsample3d) vae2_2.py:112-155."""
         T, H, W, C = x.shape
         if rs.mode == "upsample3d" and not first_chunk:
             op = self.ops[rs.time_conv]
-            ring = op.ring(H, W, tmax)
-            ring[CACHE_T:CACHE_T + T].copy_(x)
+            ring, after = self.conv_input(op, H, W, T, lambda dst: dst.copy_(x))
             x = self._conv(op, ring, CACHE_T + T, H, W, T, H, W, t_off=0, interleave=1)
-            _shift(ring, T)
+            if after is not None:
+                after()
             T = 2 * T
         # first chunk of upsample3d: the "Rep" sentinel - no time conv, cache stays at the zero padding
         return self._conv(self.ops[rs.resample[1]], x, T, H, W, T, 2 * H, 2 * W, ph=1, pw=1, up=1)
 
-    def downsample(self, rs, x, first_chunk, tmax):
+    def downsample(self, rs, x, first_chunk):
         """Resample.forward (downsample2d / downsample3d) vae2_2.py:153-169."""
         T, H, W, C = x.shape
         y = self._conv(self.ops[rs.resample[1]], x, T, H, W, T, H // 2, W // 2, sh=2, sw=2)
         if rs.mode == "downsample3d":
             op = self.ops[rs.time_conv]
-            ring = op.ring(H // 2, W // 2, tmax, prefix=1)
             if first_chunk:
-                ring[0].copy_(y[-1])                      # feat_cache[idx] = x.clone(); x passes through
+                op.cache(H // 2, W // 2, 1)[0].copy_(y[-1])       # feat_cache[idx] = x.clone(); x passes through
             else:
-                ring[1:1 + T].copy_(y)
+                ring, after = self.conv_input(op, H // 2, W // 2, T, lambda dst: dst.copy_(y), prefix=1)   # cache <- y[-1]
                 tout = (1 + T - 3) // 2 + 1
-                last = y[-1].clone()
                 y = self._conv(op, ring, 1 + T, H // 2, W // 2, tout, H // 2, W // 2, st=2, t_off=0)
-                ring[0].copy_(last)
+                if after is not None:
+                    after()
         return y
 
     # -- encoder / decoder bodies --
-    def encoder_chunk(self, vid, f0, T, first_chunk, tmax):
+    def encoder_chunk(self, vid, f0, T, first_chunk):
+        """Frames [f0, f0 + T) of the clip through the encoder (T = 1 for the first chunk, a multiple of 4 afterwards)."""
         enc = self.m.encoder
         F, Hv, Wv = vid.shape[1:]
         H, W = Hv // 2, Wv // 2
@@ -332,49 +360,42 @@ class _Engine:
         def fill(dst):
             _lib.call("uv_vae_video_in", _lib.ptr(vid), _lib.ptr(dst), dst.stride(-2), F, Hv, Wv, f0, T, _lib.stream_ptr())
 
-        x = self.causal_conv(enc.conv1, fill, T, H, W, tmax)
+        x = self.causal_conv(enc.conv1, fill, T, H, W)
         for stage in enc.downsamples:
             x_copy = x
             for mod in stage.downsamples:
-                x = self.resblock(mod, x, tmax) if isinstance(mod, ResidualBlock) else self.downsample(mod, x, first_chunk, tmax)
+                x = self.resblock(mod, x) if isinstance(mod, ResidualBlock) else self.downsample(mod, x, first_chunk)
             Tc, Hc, Wc, Cc = x_copy.shape
             _lib.call("uv_vae_avgdown_add", _lib.ptr(x_copy), _lib.ptr(x), Tc, Hc, Wc, Cc, stage.out_dim, stage.factor_t,
                       stage.factor_s, _lib.stream_ptr())
-        x = self.resblock(enc.middle[0], x, tmax)
+        x = self.resblock(enc.middle[0], x)
         x = self.attention(enc.middle[1], x)
-        x = self.resblock(enc.middle[2], x, tmax)
+        x = self.resblock(enc.middle[2], x)
         T2, H2, W2, _ = x.shape
         sp = self.precision == "bf16x3" and x.shape[-1] % 32 == 0
-        return self.causal_conv(enc.head[2], lambda dst: self._rms_silu(x, enc.head[0].gamma, dst, split=sp), T2, H2, W2, tmax,
-                                in_split=sp)
+        return self.causal_conv(enc.head[2], lambda dst: self._rms_silu(x, enc.head[0].gamma, dst, split=sp), T2, H2, W2, in_split=sp)
 
     def decoder_chunk(self, xin, first_chunk):
-        """xin: [1, h, w, z] rows of conv2's output for one latent frame -> [T, 8h, 8w, 12]."""
+        """xin: [T0, h, w, z] rows of conv2's output for T0 latent frames (T0 = 1 for the first chunk) -> [T, 8h, 8w, 12]."""
         dec = self.m.decoder
-        _, H, W, _ = xin.shape
-        x = self.causal_conv(dec.conv1, lambda dst: dst[..., :xin.shape[-1]].copy_(xin), 1, H, W, 1)
-        x = self.resblock(dec.middle[0], x, 1)
+        T0, H, W, _ = xin.shape
+        x = self.causal_conv(dec.conv1, lambda dst: dst[..., :xin.shape[-1]].copy_(xin), T0, H, W)
+        x = self.resblock(dec.middle[0], x)
         x = self.attention(dec.middle[1], x)
-        x = self.resblock(dec.middle[2], x, 1)
-        tmax = 1
+        x = self.resblock(dec.middle[2], x)
         for stage in dec.upsamples:
             xm = x
             for mod in stage.upsamples:
-                if isinstance(mod, ResidualBlock):
-                    xm = self.resblock(mod, xm, tmax)
-                else:
-                    xm = self.upsample(mod, xm, first_chunk, tmax)
+                xm = self.resblock(mod, xm) if isinstance(mod, ResidualBlock) else self.upsample(mod, xm, first_chunk)
             if stage.up_flag:
                 T, Hh, Ww, C = x.shape
                 ft = stage.factor_t
                 _lib.call("uv_vae_dupup_add", _lib.ptr(x), _lib.ptr(xm), T, Hh, Ww, C, stage.out_dim, ft,
                           (ft - 1) if first_chunk else 0, _lib.stream_ptr())
-                tmax *= ft
             x = xm
         T, Hh, Ww, _ = x.shape
         sp = self.precision == "bf16x3" and x.shape[-1] % 32 == 0
-        return self.causal_conv(dec.head[2], lambda dst: self._rms_silu(x, dec.head[0].gamma, dst, split=sp), T, Hh, Ww, tmax,
-                                in_split=sp)
+        return self.causal_conv(dec.head[2], lambda dst: self._rms_silu(x, dec.head[0].gamma, dst, split=sp), T, Hh, Ww, in_split=sp)
 
 
 class WanVAE_(nn.Module):
@@ -391,6 +412,11 @@ class WanVAE_(nn.Module):
         self.decoder = Decoder3d(dec_dim, z_dim, dim_mult, num_res_blocks, attn_scales, self.temperal_upsample, dropout)
         self._engine = None
         self.precision = "fp32"
+        # Latent frames per decoder pass / 4-frame chunks per encoder pass after the first chunk. The reference streams ONE at a
+        # time (vae2_2.py:797-806, 824-835) to bound memory; every layer is time-causal with a 2-frame cache, so longer passes
+        # compute the same values (bit-identical here: tested) with fewer, larger launches (grid quantisation on 256 CUs, launch
+        # count). 4 keeps the largest decoder tensors of a 720p clip at 4-8 GB; 1 reproduces the reference's streaming granularity.
+        self.frames_per_pass = 4
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
 
     def invalidate(self):
@@ -422,10 +448,11 @@ class WanVAE_(nn.Module):
         eng.reset()
         vid = x[0].contiguous().float()
         F = vid.shape[1]
-        outs = []
-        for i in range(1 + (F - 1) // 4):
-            f0, T = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4)
-            outs.append(eng.encoder_chunk(vid, f0, T, first_chunk=(i == 0), tmax=4))
+        outs = [eng.encoder_chunk(vid, 0, 1, first_chunk=True)]
+        n4, G = (F - 1) // 4, max(1, int(self.frames_per_pass))                  # 4-frame chunks after the first frame
+        for c0 in range(0, n4, G):
+            g = min(G, n4 - c0)
+            outs.append(eng.encoder_chunk(vid, 1 + 4 * c0, 4 * g, first_chunk=False))
         out = torch.cat(outs, 0)                                                  # [f, h, w, 2z]
         y = eng._pointwise(eng.ops[self.conv1], out)                              # 1x1x1, then chunk(2) -> mu
         f, h, w, _ = y.shape
@@ -448,8 +475,9 @@ class WanVAE_(nn.Module):
         F = 4 * (f - 1) + 1
         vid = torch.empty(1, 3, F, 16 * h, 16 * w, dtype=torch.float32, device=zz.device)
         f0 = 0
-        for i in range(f):
-            y = eng.decoder_chunk(x[i:i + 1], first_chunk=(i == 0))              # [T, 8h, 8w, 12]
+        G = max(1, int(self.frames_per_pass))
+        for i0, i1 in [(0, 1)] + [(i, min(i + G, f)) for i in range(1, f, G)]:
+            y = eng.decoder_chunk(x[i0:i1], first_chunk=(i0 == 0))               # [T, 8h, 8w, 12]
             T = y.shape[0]
             _lib.call("uv_vae_video_out", _lib.ptr(y), y.stride(-2), _lib.ptr(vid), F, 8 * h, 8 * w, f0, T, _lib.stream_ptr())
             f0 += T
@@ -469,7 +497,7 @@ class Wan2_2_VAE:
     a path loads the reference checkpoint (same state-dict keys)."""
 
     def __init__(self, z_dim=48, c_dim=160, vae_pth=None, dim_mult=(1, 2, 4, 4), temperal_downsample=(False, True, True),
-                 dtype=torch.float, device="cuda", dec_dim=256, seed=0, precision="fp32"):
+                 dtype=torch.float, device="cuda", dec_dim=256, seed=0, precision="fp32", frames_per_pass=None):
         self.dtype = dtype
         self.device = torch.device(device)
         mean = torch.tensor(_MEAN, dtype=dtype, device=device)
@@ -485,6 +513,8 @@ class Wan2_2_VAE:
             model.init_weights(seed)
         self.model = model.eval().requires_grad_(False).to(device)
         self.model.precision = precision
+        if frames_per_pass is not None:      # latent frames per decoder pass (WanVAE_.frames_per_pass; 1 = the reference's streaming)
+            self.model.frames_per_pass = int(frames_per_pass)
 
     def encode(self, videos):
         """List in, list out; a non-list argument is logged and answered with None, as the reference does (vae2_2.py:1024-1036:
