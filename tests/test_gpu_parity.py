@@ -1480,7 +1480,7 @@ def test_vae_pass_length_does_not_change_the_result():
     z = torch.randn(48, 6, 2, 3, generator=g)                    # 6 latent frames -> 21 output frames
     vid = torch.tanh(torch.randn(3, 21, 32, 48, generator=g))    # 1 + 5 chunks of 4 frames
     z2 = torch.randn(48, 3, 3, 2, generator=g)
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "bf16x6", "bf16x3"):
         ref = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=3, precision=prec, frames_per_pass=1)
         with torch.no_grad():
             d1, e1, d1b = ref.decode([z.to(DEV)])[0], ref.encode([vid.to(DEV)])[0], ref.decode([z2.to(DEV)])[0]
@@ -1513,6 +1513,23 @@ def test_vae_bf16x3_precision_mode():
         assert not torch.equal(fast.decode([g["dec_in_0"].to(DEV)])[0], exact.decode([g["dec_in_0"].to(DEV)])[0])
 
 
+def test_vae_bf16x6_precision_mode_vs_golden():
+    """precision='bf16x6' (f32-grade arithmetic on the bf16 matrix pipe): the small-VAE goldens at the same tolerance as fp32."""
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    g = load_golden("vae_small")
+    vae = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=g["seed"], precision="bf16x6")
+    exact = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=g["seed"])
+    for i in range(3):
+        with torch.no_grad():
+            v, z = vae.decode([g[f"dec_in_{i}"].to(DEV)])[0], vae.encode([g[f"enc_in_{i}"].to(DEV)])[0]
+            v0, z0 = exact.decode([g[f"dec_in_{i}"].to(DEV)])[0], exact.encode([g[f"enc_in_{i}"].to(DEV)])[0]
+        assert_f32_close(v, g[f"dec_out_{i}"], name=f"bf16x6 decode {i}")
+        assert_f32_close(z, g[f"enc_out_{i}"], name=f"bf16x6 encode {i}")
+        # and as close to the reference output as the exact-f32 mode is (both differ from it by accumulation order only)
+        e6, e0 = (v.cpu() - g[f"dec_out_{i}"]).abs().max().item(), (v0.cpu() - g[f"dec_out_{i}"]).abs().max().item()
+        assert e6 < 2.0 * e0 + 1e-6, (i, e6, e0)
+
+
 def test_vae_full_width_vs_oracle():
     """The production VAE widths (encoder 160..640, decoder 1024..256 channels, z = 48) on a small clip, fp32 mode and
     bf16x3 mode, against the CPU oracle run here."""
@@ -1528,7 +1545,7 @@ def test_vae_full_width_vs_oracle():
     with torch.no_grad():
         ref_dec = wan_vae.vae_decode(ora, [z])[0]
         ref_enc = wan_vae.vae_encode(ora, [vid])[0]
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "bf16x6", "bf16x3"):
         vae = Wan2_2_VAE(device=DEV, precision=prec)
         vae.model.load_state_dict(sd)
         with torch.no_grad():
@@ -1536,8 +1553,10 @@ def test_vae_full_width_vs_oracle():
             assert_f32_close(vae.encode([vid.to(DEV)])[0], ref_enc, name=f"full-width encode {prec}")
 
 
-def test_conv3d_kernel_geometries():
-    """Every convolution geometry the VAE uses, against F.conv3d / F.conv2d."""
+@pytest.mark.parametrize("entry", ["uv_conv3d_f32", "uv_conv3d_bf16x6"])
+def test_conv3d_kernel_geometries(entry):
+    """Every convolution geometry the VAE uses, against F.conv3d / F.conv2d: the exact-f32 MFMA kernel and the same kernel with
+    the products on the bf16 matrix pipe by exact three-way operand splitting (same memory formats, same tolerance)."""
     import torch.nn.functional as F
     from univid_amd import _lib
     g = torch.Generator().manual_seed(4)
@@ -1548,7 +1567,7 @@ def test_conv3d_kernel_geometries():
         wp = w.permute(0, 2, 3, 4, 1).reshape(co, -1).contiguous().to(DEV)
         inter = kw.get("interleave", 0)
         out = torch.empty(Tout * (2 if inter else 1), Hout, Wout, co // (2 if inter else 1), device=DEV)
-        _lib.call("uv_conv3d_f32", _lib.ptr(x_cl), C, T, H, W, _lib.ptr(wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), out.shape[-1],
+        _lib.call(entry, _lib.ptr(x_cl), C, T, H, W, _lib.ptr(wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), out.shape[-1],
                   Tout, Hout, Wout, C, co, kt, kh, kw_, kw.get("st", 1), kw.get("sh", 1), kw.get("sw", 1), kw.get("t_off", 0),
                   kw.get("ph", 0), kw.get("pw", 0), kw.get("up", 0), inter, None, 0, _lib.stream_ptr())
         return out.cpu()
@@ -1584,6 +1603,37 @@ def test_conv3d_kernel_geometries():
         ref = F.conv3d(F.pad(xl, (1, 1, 1, 1, 2, 0)), wc, bc)
         got = run(cl(F.pad(xl, (0, 0, 0, 0, 2, 0))), wc, bc, 3, 19, 23, ph=1, pw=1)
         assert_f32_close(got.permute(3, 0, 1, 2), ref[0], rtol=1e-4, atol=1e-4, name=f"3x3x3, Cout {co}")
+
+
+def test_conv3d_bf16x6_is_f32_grade():
+    """uv_conv3d_bf16x6 (three bf16 planes per f32 operand, the six product terms with i + j <= 2, f32 accumulate) against an fp64
+    convolution of the same f32 operands, next to the exact-f32 MFMA kernel: at the decoder's channel counts (K = 27 C up to 27 648)
+    its error must not exceed the f32 kernel's (measured: 0.87-0.89 x) - it is the f32 arithmetic on another pipe, not a narrower
+    one (the 2-way split bf16x3 drops the lo.lo term and is ~20 x further from fp64)."""
+    import torch.nn.functional as F
+    from univid_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    meas = {}
+    for C, co in ((256, 256), (1024, 1024)):
+        T, H, W = 2, 12, 16
+        x = F.silu(torch.randn(1, C, T + 2, H, W, generator=g))
+        w = torch.randn(co, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5
+        b = torch.randn(co, generator=g) * 0.1
+        ref = F.conv3d(F.pad(x.double(), (1, 1, 1, 1, 0, 0)), w.double(), b.double())[0].permute(1, 2, 3, 0)
+        x_cl = x[0].permute(1, 2, 3, 0).contiguous().to(DEV)
+        wp = w.permute(0, 2, 3, 4, 1).reshape(co, -1).contiguous().to(DEV)
+        err = {}
+        for name in ("uv_conv3d_f32", "uv_conv3d_bf16x6"):
+            out = torch.empty(T, H, W, co, device=DEV)
+            _lib.call(name, _lib.ptr(x_cl), C, T + 2, H, W, _lib.ptr(wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), co, T, H, W, C, co, 3, 3, 3,
+                      1, 1, 1, 0, 1, 1, 0, 0, None, 0, _lib.stream_ptr())
+            d = out.cpu().double() - ref
+            err[name] = float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        meas[f"C{C}_f32_mfma_rel_rms_vs_fp64"] = err["uv_conv3d_f32"]
+        meas[f"C{C}_bf16x6_rel_rms_vs_fp64"] = err["uv_conv3d_bf16x6"]
+        assert err["uv_conv3d_bf16x6"] <= 1.05 * err["uv_conv3d_f32"], (C, err)
+        assert err["uv_conv3d_bf16x6"] < 5e-6
+    record_margin("conv3d 3x3x3: error against fp64 (exact-f32 MFMA vs bf16x6)", **meas)
 
 
 # ---------------------------------------------------------------------------------------------------------------

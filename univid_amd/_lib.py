@@ -53,6 +53,8 @@ SIGNATURES = {
     "uv_dpmpp_update": [_P, _P, _P, _P, _F, _F, _F, _I, _L, _P],
     "uv_conv3d_f32": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                       _P, _L, _P],
+    "uv_conv3d_bf16x6": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                         _P, _L, _P],
     "uv_conv3d_bf16x3": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                          _P, _L, _I, _P],
     "uv_split_weights_bf16x3": [_P, _P, _L, _P],

@@ -191,6 +191,49 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
                         for (int j = 0; j < TM; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], af[j][e], acc[i][j], 0, 0, 0);
             }
+        } else if (PREC == 3) {
+            // "bf16x6": BOTH operands stay f32 in HBM and LDS (staging identical to PREC 0) and are split in registers into three
+            // bf16 planes each, x = x0 + x1 + x2 with round-to-nearest at every level (|x1| <= 2^-9 |x|, |x2| <= 2^-18 |x|, and the
+            // three planes hold all 24 significand bits: the decomposition is exact). The product keeps the six terms with
+            // i + j <= 2; the dropped ones (x1 w2, x2 w1, x2 w2) are below 2^-26 |x w|, i.e. under the f32 rounding of the product
+            // itself. Terms are accumulated smallest first on the f32 accumulators of the bf16 MFMA.
+            bf16x8 ap[TM][3], wp[TN][3];
+            auto split8 = [](const f32x4& x0, const f32x4& x1, bf16x8* out3) {
+                float r[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { r[e] = x0[e]; r[4 + e] = x1[e]; }
+#pragma unroll
+                for (int lvl = 0; lvl < 3; ++lvl)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const __bf16 hq = (__bf16)r[e];
+                        out3[lvl][e] = hq;
+                        if (lvl < 2) r[e] = r[e] - (float)hq;
+                    }
+            };
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const f32x4 x0 = *(const f32x4*)(base + a_off[j] + (((2 * fq) ^ a_key[j]) << 4));
+                const f32x4 x1 = *(const f32x4*)(base + a_off[j] + (((2 * fq + 1) ^ a_key[j]) << 4));
+                split8(x0, x1, ap[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const f32x4 x0 = *(const f32x4*)(base + w_off[i] + (((2 * fq) ^ w_key[i]) << 4));
+                const f32x4 x1 = *(const f32x4*)(base + w_off[i] + (((2 * fq + 1) ^ w_key[i]) << 4));
+                split8(x0, x1, wp[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][2], ap[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][1], ap[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][0], ap[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][1], ap[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][0], ap[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][0], ap[j][0], acc[i][j], 0, 0, 0);
+                }
         } else {
             // one K = 32 MFMA step per k-tile: lane (row, fq) owns k = 8*fq .. 8*fq+7 of both operands
             bf16x8 ah[TM], al[TM], wh[TN], wl[TN];
@@ -314,6 +357,10 @@ static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, c
         if (Cout <= 16) launch_conv<256, 16, 4, 1, 0>(a, s);
         else if (Cout % 160 == 0 && Cout % 128 != 0) launch_conv<128, 160, 2, 2, 0>(a, s);
         else launch_conv<128, 128, 2, 2, 0>(a, s);
+    } else if (prec == 3) {
+        if (Cout <= 16) launch_conv<256, 16, 4, 1, 3>(a, s);
+        else if (Cout % 160 == 0 && Cout % 128 != 0) launch_conv<128, 160, 2, 2, 3>(a, s);
+        else launch_conv<128, 128, 2, 2, 3>(a, s);
     } else if (prec == 1) {
         if (Cout >= 256 && t256 >= 256) launch_conv<256, 256, 4, 4, 1>(a, s);
         else if (t128 >= 256) launch_conv<256, 128, 4, 2, 1>(a, s);
@@ -333,6 +380,16 @@ extern "C" int uv_conv3d_f32(const float* in, long ld_in, int Tin, int Hin, int 
                              const float* resid, long ldr, void* stream) {
     return conv_common(in, ld_in, Tin, Hin, Win, w, bias, out, ldo, Tout, Hout, Wout, Cin, Cout, kt, kh, kw, st, sh, sw, t_off,
                        ph, pw, up, interleave, resid, ldr, 0, stream);
+}
+
+// Same convolution, same f32 operands in memory, arithmetic on the bf16 matrix pipe by exact three-way operand splitting (PREC 3 above:
+// six bf16 MFMA passes per product, f32 accumulate; per-product error below 2^-26, under f32's own rounding).
+extern "C" int uv_conv3d_bf16x6(const float* in, long ld_in, int Tin, int Hin, int Win, const float* w, const float* bias,
+                                float* out, long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh,
+                                int kw, int st, int sh, int sw, int t_off, int ph, int pw, int up, int interleave,
+                                const float* resid, long ldr, void* stream) {
+    return conv_common(in, ld_in, Tin, Hin, Win, w, bias, out, ldo, Tout, Hout, Wout, Cin, Cout, kt, kh, kw, st, sh, sw, t_off,
+                       ph, pw, up, interleave, resid, ldr, 3, stream);
 }
 
 // Same convolution with split-bf16 (3-pass) arithmetic. w_split: [Cout][K/32][32 hi | 32 lo] bf16 (uv_split_weights_bf16x3).
