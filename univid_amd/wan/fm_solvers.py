@@ -23,29 +23,23 @@ def get_sampling_sigmas(sampling_steps, shift):
 
 
 def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **kwargs):
-    """fm_solvers.py:31-68: calls `scheduler.set_timesteps` with custom timesteps or sigmas and returns
-    (scheduler.timesteps, num_inference_steps)."""
+    """fm_solvers.py:31-68: hands a custom `timesteps` or `sigmas` schedule (or a plain step count) to
+    `scheduler.set_timesteps` and returns `(scheduler.timesteps, number of steps)`. ValueError if both custom schedules are
+    given, or if the scheduler's `set_timesteps` has no such parameter."""
     if timesteps is not None and sigmas is not None:
-        raise ValueError("Only one of `timesteps` or `sigmas` can be passed. Please choose one to set custom values")
-    params = set(inspect.signature(scheduler.set_timesteps).parameters.keys())
-    if timesteps is not None:
-        if "timesteps" not in params:
-            raise ValueError(f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom"
-                             f" timestep schedules. Please check whether you are using the correct scheduler.")
-        scheduler.set_timesteps(timesteps=timesteps, device=device, **kwargs)
-        timesteps = scheduler.timesteps
-        num_inference_steps = len(timesteps)
-    elif sigmas is not None:
-        if "sigmas" not in params:
-            raise ValueError(f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom"
-                             f" sigmas schedules. Please check whether you are using the correct scheduler.")
-        scheduler.set_timesteps(sigmas=sigmas, device=device, **kwargs)
-        timesteps = scheduler.timesteps
-        num_inference_steps = len(timesteps)
-    else:
-        scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
-        timesteps = scheduler.timesteps
-    return timesteps, num_inference_steps
+        raise ValueError("pass either `timesteps` or `sigmas`, not both")
+    accepted = inspect.signature(scheduler.set_timesteps).parameters
+    custom = {"timesteps": timesteps, "sigmas": sigmas}
+    for name, value in custom.items():
+        if value is None:
+            continue
+        if name not in accepted:
+            raise ValueError(f"{type(scheduler).__name__}.set_timesteps takes no `{name}` argument: this scheduler cannot run a "
+                             f"custom {name} schedule")
+        scheduler.set_timesteps(device=device, **{name: value}, **kwargs)
+        return scheduler.timesteps, len(scheduler.timesteps)
+    scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
+    return scheduler.timesteps, num_inference_steps
 
 
 class FlowDPMSolverMultistepScheduler:
