@@ -20,3 +20,11 @@ with torch.no_grad():
     t0 = time.time(); v = vae.decode([zr])[0]; torch.cuda.synchronize(); print("hip decode", time.time() - t0, flush=True)
     t0 = time.time(); vr = ora.decode(zr.unsqueeze(0), scale).float().clamp_(-1, 1).squeeze(0); torch.cuda.synchronize(); print("eager decode", time.time() - t0, flush=True)
     d = (v - vr).abs(); print("decode max abs", float(d.max()), "outside 1e-3/1e-4:", int((d > 1e-4 + 1e-3 * vr.abs()).sum()), "of", d.numel(), flush=True)
+    # the f32-grade bf16x6 arithmetic at the same resolution: against the same eager-oracle outputs and against the exact-f32 HIP mode
+    vae6 = Wan2_2_VAE(device=dev, seed=2, precision="bf16x6")
+    z6 = vae6.encode([vid])[0]
+    d = (z6 - zr).abs(); print("bf16x6 encode max abs", float(d.max()), "outside 1e-3/1e-4:", int((d > 1e-4 + 1e-3 * zr.abs()).sum()),
+                               "| vs exact-f32 HIP: max abs", float((z6 - z).abs().max()), flush=True)
+    v6 = vae6.decode([zr])[0]
+    d = (v6 - vr).abs(); print("bf16x6 decode max abs", float(d.max()), "outside 1e-3/1e-4:", int((d > 1e-4 + 1e-3 * vr.abs()).sum()), "of", d.numel(),
+                               "| vs exact-f32 HIP: max abs", float((v6 - v).abs().max()), flush=True)
