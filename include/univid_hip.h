@@ -171,12 +171,16 @@ int uv_dpmpp_update(const float* x, const float* m0, const float* m1, float* out
 int uv_conv3d_f32(const float* in, long ld_in, int Tin, int Hin, int Win, const float* w, const float* bias, float* out,
                   long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw,
                   int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr, void* stream);
-/* uv_conv3d_f32 with the products computed on the bf16 matrix pipe by exact three-way splitting of BOTH f32 operands in registers
- * (x = x0 + x1 + x2, round-to-nearest bf16 planes; the six terms with i + j <= 2; f32 accumulate): same memory formats as
- * uv_conv3d_f32, per-product error below 2^-26 (under f32 rounding). Replaces the same reference lines as uv_conv3d_f32. */
-int uv_conv3d_bf16x6(const float* in, long ld_in, int Tin, int Hin, int Win, const float* w, const float* bias, float* out, long ldo,
+/* uv_conv3d_f32 with the products computed on the bf16 matrix pipe by exact three-way splitting of both f32 operands (x = x0 + x1 + x2,
+ * round-to-nearest bf16 planes; the six terms with i + j <= 2; f32 accumulate): per-product error below 2^-26 (under f32 rounding).
+ * Activations / bias / residual / output as in uv_conv3d_f32 (split in registers); w_split6 = uv_split_weights_bf16x6 of the f32
+ * weights. Replaces the same reference lines as uv_conv3d_f32. */
+int uv_conv3d_bf16x6(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w_split6, const float* bias, float* out, long ldo,
                      int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw, int t_off, int ph,
                      int pw, int up, int interleave, const float* resid, long ldr, void* stream);
+/* w [rows][K] f32 (K % 32 == 0) -> [rows][K/32][32 p0 | 32 p1 | 32 p2] bf16, w = p0 + p1 + p2 exactly (n = rows * K elements in,
+ * 3 n bf16 out). */
+int uv_split_weights_bf16x6(const float* w, void* out, long n, void* stream);
 /* The same convolution in split-bf16 ("bf16x3") arithmetic: x*w ~ xh*wh + xh*wl + xl*wh on the bf16 MFMA with f32 accumulate
  * (relative error per product ~1e-5; up to 16/3 x the f32-MFMA rate). w_split comes from uv_split_weights_bf16x3.
  * in_split=1: the input ring already holds split activations ([C/32][32 hi | 32 lo] bf16 per pixel, as written by

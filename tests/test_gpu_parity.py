@@ -1553,6 +1553,16 @@ def test_vae_full_width_vs_oracle():
             assert_f32_close(vae.encode([vid.to(DEV)])[0], ref_enc, name=f"full-width encode {prec}")
 
 
+def _split6(wp):
+    """uv_split_weights_bf16x6 of a [Cout, K] f32 weight matrix (+ a check that the three planes sum back to it exactly)."""
+    from univid_amd import _lib
+    out = torch.empty(wp.numel() * 3, dtype=BF16, device=wp.device)
+    _lib.call("uv_split_weights_bf16x6", _lib.ptr(wp), _lib.ptr(out), wp.numel(), _lib.stream_ptr())
+    pl = out.view(wp.shape[0], -1, 3, 32).float()
+    assert torch.equal((pl[:, :, 0] + pl[:, :, 1]) + pl[:, :, 2], wp.view(wp.shape[0], -1, 32)), "w != p0 + p1 + p2"
+    return out
+
+
 @pytest.mark.parametrize("entry", ["uv_conv3d_f32", "uv_conv3d_bf16x6"])
 def test_conv3d_kernel_geometries(entry):
     """Every convolution geometry the VAE uses, against F.conv3d / F.conv2d: the exact-f32 MFMA kernel and the same kernel with
@@ -1565,6 +1575,8 @@ def test_conv3d_kernel_geometries(entry):
         T, H, W, C = x_cl.shape
         co, ci, kt, kh, kw_ = w.shape
         wp = w.permute(0, 2, 3, 4, 1).reshape(co, -1).contiguous().to(DEV)
+        if entry == "uv_conv3d_bf16x6":
+            wp = _split6(wp)
         inter = kw.get("interleave", 0)
         out = torch.empty(Tout * (2 if inter else 1), Hout, Wout, co // (2 if inter else 1), device=DEV)
         _lib.call(entry, _lib.ptr(x_cl), C, T, H, W, _lib.ptr(wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), out.shape[-1],
@@ -1625,7 +1637,7 @@ def test_conv3d_bf16x6_is_f32_grade():
         err = {}
         for name in ("uv_conv3d_f32", "uv_conv3d_bf16x6"):
             out = torch.empty(T, H, W, co, device=DEV)
-            _lib.call(name, _lib.ptr(x_cl), C, T + 2, H, W, _lib.ptr(wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), co, T, H, W, C, co, 3, 3, 3,
+            _lib.call(name, _lib.ptr(x_cl), C, T + 2, H, W, _lib.ptr(_split6(wp) if name.endswith("x6") else wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), co, T, H, W, C, co, 3, 3, 3,
                       1, 1, 1, 0, 1, 1, 0, 0, None, 0, _lib.stream_ptr())
             d = out.cpu().double() - ref
             err[name] = float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())

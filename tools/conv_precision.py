@@ -7,9 +7,16 @@ from univid_amd import _lib
 _lib.init()
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
+_SPLIT = {}
 
 
 def run(name, x_cl, wp, b, out, T, H, W, C, co):
+    if name.endswith("x6"):
+        key = wp.data_ptr()
+        if key not in _SPLIT:
+            _SPLIT[key] = torch.empty(wp.numel() * 3, dtype=torch.bfloat16, device=dev)
+            _lib.call("uv_split_weights_bf16x6", _lib.ptr(wp), _lib.ptr(_SPLIT[key]), wp.numel(), _lib.stream_ptr())
+        wp = _SPLIT[key]
     _lib.call(name, _lib.ptr(x_cl), C, T + 2, H, W, _lib.ptr(wp), _lib.ptr(b), _lib.ptr(out), co, T, H, W, C, co, 3, 3, 3, 1, 1, 1, 0, 1, 1,
               0, 0, None, 0, _lib.stream_ptr())
 

@@ -47,8 +47,10 @@ template <int BM, int BN, int WM, int WN, int PREC>
 __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-    constexpr int A_INSTR = BM / 8 / NW, W_INSTR = (BN / 8 + NW - 1) / NW;   // a narrow W tile (BN = 16) is staged by the first waves only
+    // PREC 3 stages the weights as three bf16 planes (64-byte rows, one [BN][64 B] sub-tile per plane) instead of f32 rows
+    constexpr int A_BYTES = BM * 128, W_BYTES = PREC == 3 ? BN * 192 : BN * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int W_PIECES = PREC == 3 ? 3 * (BN / 16) : BN / 8;             // 1-KiB LDS-DMA pieces per W tile and k-tile
+    constexpr int A_INSTR = BM / 8 / NW, W_INSTR = (W_PIECES + NW - 1) / NW;  // a narrow W tile (BN = 16) is staged by the first waves only
     static_assert(BM % (8 * NW) == 0, "A tile rows must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -74,11 +76,26 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
     }
     const float* w_src[W_INSTR];
     int w_c[W_INSTR];
+    int w_dst[W_INSTR];            // LDS byte offset of the piece inside the W tile
 #pragma unroll
     for (int i = 0; i < W_INSTR; ++i) {
-        const int row = (i * NW + wave) * 8 + srow;
-        w_c[i] = (pchunk ^ ((row >> 1) & 7)) * 4;
-        w_src[i] = p.w + (long)min(n0 + row, p.Cout - 1) * K + w_c[i];
+        const int pi = i * NW + wave;
+        if constexpr (PREC == 3) {
+            // piece = 16 rows x 64 B of ONE plane; lane (row = lane / 4, slot = lane % 4) fetches chunk slot ^ swz(row) so that the
+            // fragment reads below (16 lanes of a ds_read_b128 group span rows 4 apart at a 64-byte row stride) are conflict-free
+            const int plane = pi / (BN / 16), rblk = pi % (BN / 16);
+            const int row = rblk * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3);          // swz(q) = {0, 2, 3, 1}[q]
+            w_c[i] = 0;
+            w_dst[i] = plane * (BN * 64) + rblk * 1024;
+            // split weights: [Cout][K / 32][32 p0 | 32 p1 | 32 p2] bf16 = 48 f32-sized units per 32 k; p.w is typed float*
+            w_src[i] = p.w + ((long)min(n0 + row, p.Cout - 1) * (K / 32) * 48 + plane * 16 + chunk * 4);
+        } else {
+            const int row = pi * 8 + srow;
+            w_c[i] = (pchunk ^ ((row >> 1) & 7)) * 4;
+            w_dst[i] = pi * 1024;
+            w_src[i] = p.w + (long)min(n0 + row, p.Cout - 1) * K + w_c[i];
+        }
     }
     const int Hlim = p.up ? 2 * p.Hin : p.Hin, Wlim = p.up ? 2 * p.Win : p.Win;
     const long frame = (long)p.Hin * p.Win * p.ld_in;
@@ -132,11 +149,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
                 __builtin_amdgcn_global_load_lds(src, (lds_void_c*)(sbase + (i * NW + wave) * 1024), 16, 0, 0);       \
             }                                                                                                         \
         }                                                                                                             \
-        const int koff = (KT) * 32;                                                                                   \
+        const int koff = (KT) * (PREC == 3 ? 48 : 32);                                                                \
         _Pragma("unroll") for (int i = 0; i < W_INSTR; ++i) {                                                         \
             const float* wsrc = w_src[i] + koff;                                                                      \
-            if ((BN / 8) % NW == 0 || (i * NW + wave) * 8 < BN)                                                       \
-                __builtin_amdgcn_global_load_lds(wsrc, (lds_void_c*)(sbase + A_BYTES + (i * NW + wave) * 1024), 16, 0, 0);\
+            if (W_PIECES % NW == 0 || i * NW + wave < W_PIECES)                                                       \
+                __builtin_amdgcn_global_load_lds(wsrc, (lds_void_c*)(sbase + A_BYTES + w_dst[i]), 16, 0, 0);          \
         }                                                                                                             \
         s_ci += 32;                                                                                                   \
         if (s_ci >= p.Cin) {                                                                                          \
@@ -163,7 +180,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
         const int row = wn * (BN / WN) + i * 16 + frow;
-        w_off[i] = A_BYTES + row * 128; w_key[i] = (row >> 1) & 7;
+        if constexpr (PREC == 3) {   // plane 0 address of this lane's 16-byte k-chunk (planes follow at BN * 64 bytes)
+            w_off[i] = A_BYTES + row * 64 + ((fq ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3)) << 4);
+            w_key[i] = 0;
+        } else {
+            w_off[i] = A_BYTES + row * 128; w_key[i] = (row >> 1) & 7;
+        }
     }
 
     const int nk = K / 32;
@@ -192,9 +214,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], af[j][e], acc[i][j], 0, 0, 0);
             }
         } else if (PREC == 3) {
-            // "bf16x6": BOTH operands stay f32 in HBM and LDS (staging identical to PREC 0) and are split in registers into three
-            // bf16 planes each, x = x0 + x1 + x2 with round-to-nearest at every level (|x1| <= 2^-9 |x|, |x2| <= 2^-18 |x|, and the
-            // three planes hold all 24 significand bits: the decomposition is exact). The product keeps the six terms with
+            // "bf16x6": every f32 operand is three bf16 planes, x = x0 + x1 + x2 with round-to-nearest at every level (|x1| <= 2^-9 |x|,
+            // |x2| <= 2^-18 |x|, and the three planes hold all 24 significand bits: the decomposition is exact). The ACTIVATIONS stay
+            // f32 in HBM and LDS (staging identical to PREC 0) and are split in registers; the WEIGHTS are split once on the host
+            // (uv_split_weights_bf16x6) and staged as planes - splitting both in registers made the kernel VALU-bound (11 vector
+            // instructions per operand pair: 74 ms for the 16 x 360 x 640, 256 -> 256 layer; 60 ms with the weight half gone).
+            // The product keeps the six terms with
             // i + j <= 2; the dropped ones (x1 w2, x2 w1, x2 w2) are below 2^-26 |x w|, i.e. under the f32 rounding of the product
             // itself. Terms are accumulated smallest first on the f32 accumulators of the bf16 MFMA.
             bf16x8 ap[TM][3], wp[TN][3];
@@ -218,11 +243,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
                 split8(x0, x1, ap[j]);
             }
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const f32x4 x0 = *(const f32x4*)(base + w_off[i] + (((2 * fq) ^ w_key[i]) << 4));
-                const f32x4 x1 = *(const f32x4*)(base + w_off[i] + (((2 * fq + 1) ^ w_key[i]) << 4));
-                split8(x0, x1, wp[i]);
-            }
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wp[i][pl] = *(const bf16x8*)(base + w_off[i] + pl * (BN * 64));
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -313,7 +336,7 @@ static void launch_conv(ConvArgs& a, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     auto kern = conv3d_f32_kernel<BM, BN, WM, WN, PREC>;
-    const size_t lds = 2 * (BM + BN) * 128;
+    const size_t lds = 2 * (BM * 128 + BN * (PREC == 3 ? 192 : 128));
     static bool attr_set[UV_MAX_DEV];
     bool& attr = attr_set[uv_cur_dev()];
     if (!attr) {
@@ -359,7 +382,8 @@ static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, c
         else launch_conv<128, 128, 2, 2, 0>(a, s);
     } else if (prec == 3) {
         if (Cout <= 16) launch_conv<256, 16, 4, 1, 3>(a, s);
-        else if (Cout % 160 == 0 && Cout % 128 != 0) launch_conv<128, 160, 2, 2, 3>(a, s);
+        // 160-wide tiles carry 30 KiB of weight planes per stage: 64 rows keep two workgroups per CU (2 x 76 KiB of LDS)
+        else if (Cout % 160 == 0 && Cout % 128 != 0) launch_conv<64, 160, 2, 2, 3>(a, s);
         else launch_conv<128, 128, 2, 2, 3>(a, s);
     } else if (prec == 1) {
         if (Cout >= 256 && t256 >= 256) launch_conv<256, 256, 4, 4, 1>(a, s);
@@ -382,14 +406,39 @@ extern "C" int uv_conv3d_f32(const float* in, long ld_in, int Tin, int Hin, int 
                        ph, pw, up, interleave, resid, ldr, 0, stream);
 }
 
-// Same convolution, same f32 operands in memory, arithmetic on the bf16 matrix pipe by exact three-way operand splitting (PREC 3 above:
-// six bf16 MFMA passes per product, f32 accumulate; per-product error below 2^-26, under f32's own rounding).
-extern "C" int uv_conv3d_bf16x6(const float* in, long ld_in, int Tin, int Hin, int Win, const float* w, const float* bias,
+// Same convolution with f32-grade arithmetic on the bf16 matrix pipe (PREC 3 above: exact three-way operand splitting, six bf16 MFMA
+// passes per product, f32 accumulate; per-product error below 2^-26, under f32's own rounding). Activations, bias, residual and output
+// are the f32 tensors of uv_conv3d_f32; w_split6 = the weights split once by uv_split_weights_bf16x6:
+// [Cout][K / 32][32 p0 | 32 p1 | 32 p2] bf16.
+extern "C" int uv_conv3d_bf16x6(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w_split6, const float* bias,
                                 float* out, long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh,
                                 int kw, int st, int sh, int sw, int t_off, int ph, int pw, int up, int interleave,
                                 const float* resid, long ldr, void* stream) {
-    return conv_common(in, ld_in, Tin, Hin, Win, w, bias, out, ldo, Tout, Hout, Wout, Cin, Cout, kt, kh, kw, st, sh, sw, t_off,
-                       ph, pw, up, interleave, resid, ldr, 3, stream);
+    return conv_common(in, ld_in, Tin, Hin, Win, w_split6, bias, out, ldo, Tout, Hout, Wout, Cin, Cout, kt, kh, kw, st, sh, sw,
+                       t_off, ph, pw, up, interleave, resid, ldr, 3, stream);
+}
+
+// w [rows][K] f32 (K % 32 == 0) -> [rows][K/32][32 p0 | 32 p1 | 32 p2] bf16 with p0 = bf16(w), p1 = bf16(w - p0), p2 = bf16(w - p0 - p1)
+// (round to nearest; w = p0 + p1 + p2 exactly)
+__global__ void split_weights6_kernel(const float* w, bf16_t* out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float r = w[i];
+        const long blk = i >> 5, e = i & 31;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const bf16_t h = f2bf(r);
+            out[blk * 96 + pl * 32 + e] = h;
+            r = r - bf2f(h);
+        }
+    }
+}
+
+extern "C" int uv_split_weights_bf16x6(const float* w, void* out, long n, void* stream) {
+    UV_CHECK_ARG(w && out && n > 0 && n % 32 == 0, "uv_split_weights_bf16x6: n must be a positive multiple of 32");
+    hipLaunchKernelGGL(split_weights6_kernel, dim3((unsigned)min((n + 255) / 256, (long)4096)), dim3(256), 0, (hipStream_t)stream, w,
+                       (bf16_t*)out, n);
+    UV_CHECK_LAUNCH("uv_split_weights_bf16x6");
+    return 0;
 }
 
 // Same convolution with split-bf16 (3-pass) arithmetic. w_split: [Cout][K/32][32 hi | 32 lo] bf16 (uv_split_weights_bf16x3).

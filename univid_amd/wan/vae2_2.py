@@ -169,6 +169,7 @@ class _ConvOp:
         self.w2d = w.reshape(self.cout, self.cin).contiguous() if (self.kt, self.kh, self.kw) == (1, 1, 1) else None
         self.b = conv.bias.detach().float().contiguous()
         self.w_split = None
+        self.w_split6 = None
         self.caches = {}     # (H, W, prefix) -> the cached frames [prefix, H, W, cin_pad] (zeros = the causal zero padding)
         self.rings = {}      # private input rings of the few convolutions whose channel count is padded (see _Engine.conv_input)
 
@@ -178,6 +179,13 @@ class _ConvOp:
             self.w_split = torch.empty(self.w.numel() * 2, dtype=torch.bfloat16, device=self.w.device)
             _lib.call("uv_split_weights_bf16x3", _lib.ptr(self.w), _lib.ptr(self.w_split), self.w.numel(), _lib.stream_ptr())
         return self.w_split
+
+    def split6(self):
+        """three bf16 planes of the weights for the bf16x6 kernel ([Cout][K/32][32 p0 | 32 p1 | 32 p2], w = p0 + p1 + p2 exactly)."""
+        if self.w_split6 is None:
+            self.w_split6 = torch.empty(self.w.numel() * 3, dtype=torch.bfloat16, device=self.w.device)
+            _lib.call("uv_split_weights_bf16x6", _lib.ptr(self.w), _lib.ptr(self.w_split6), self.w.numel(), _lib.stream_ptr())
+        return self.w_split6
 
     def cache(self, H, W, prefix=CACHE_T):
         key = (H, W, prefix)
@@ -257,8 +265,9 @@ class _Engine:
             _lib.call("uv_conv3d_bf16x3", _lib.ptr(src), src.stride(-2), Tin, Hin, Win, _lib.ptr(op.split()), _lib.ptr(op.b),
                       _lib.ptr(out), *geom, int(in_split), _lib.stream_ptr(), flops=flops)
         else:
-            _lib.call("uv_conv3d_bf16x6" if self.precision == "bf16x6" else "uv_conv3d_f32", _lib.ptr(src), src.stride(-2), Tin, Hin, Win,
-                      _lib.ptr(op.w), _lib.ptr(op.b), _lib.ptr(out), *geom, _lib.stream_ptr(), flops=flops)
+            x6 = self.precision == "bf16x6"
+            _lib.call("uv_conv3d_bf16x6" if x6 else "uv_conv3d_f32", _lib.ptr(src), src.stride(-2), Tin, Hin, Win,
+                      _lib.ptr(op.split6() if x6 else op.w), _lib.ptr(op.b), _lib.ptr(out), *geom, _lib.stream_ptr(), flops=flops)
         return out
 
     def _rms_silu(self, x, gamma, out, silu=True, split=False):
@@ -426,7 +435,7 @@ class WanVAE_(nn.Module):
     def prepare(self, precision=None):
         """precision: 'fp32' = exact f32 MFMA (the reference's dtype, default) | 'bf16x6' = the same f32 operands, products on the
         bf16 matrix pipe by exact three-way operand splitting (6 passes; as close to an fp64 convolution as the f32 MFMA kernel,
-        1.3 x faster) | 'bf16x3' = two-way split, 3 passes (~1e-5 relative error, several times faster). The 1x1 convolutions,
+        1.45 x faster) | 'bf16x3' = two-way split, 3 passes (~1e-5 relative error, several times faster). The 1x1 convolutions,
         norms and the per-frame attention stay on the f32 kernels in every mode."""
         if next(self.parameters()).device.type != "cuda":
             raise _lib.UnividHipError("WanVAE_.prepare: parameters must be on the GPU - there is no CPU path in univid_amd")
