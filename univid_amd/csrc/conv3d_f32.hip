@@ -1,5 +1,5 @@
 // Causal 3D / 2D convolution of the Wan2.2 VAE as an implicit GEMM on the exact-f32 MFMA
-// (v_mfma_f32_16x16x4_f32), channels-last activations.
+// (v_mfma_f32_16x16x4_f32; opt-in: the same f32 products on the bf16 MFMA, PREC 3 / PREC 1-2 below), channels-last activations.
 //
 //   out[pixel, co] = bias[co] + sum_{tap, ci} in[pixel + tap, ci] * w[co, tap, ci]   (+ residual)
 //   M = output pixels (t, h, w), N = Cout, K = taps * Cin; A rows are GATHERED straight from the input
@@ -43,6 +43,9 @@ struct ConvArgs {
 //         is shared); activations stay f32 in HBM/LDS and are split in registers.
 // PREC 2: bf16x3 with the ACTIVATIONS pre-split too (the producer, uv_vae_rms_silu, writes [C/32][32 hi | 32 lo] bf16 into
 //         the input ring: same bytes per pixel as f32): no conversion work in the MFMA loop at all.
+// PREC 3: "bf16x6", f32-GRADE: every f32 operand is three bf16 planes (x = x0 + x1 + x2 exactly) and the product keeps the six
+//         terms with i + j <= 2 (error < 2^-26 |x w|, under f32's own rounding), f32 accumulate. Activations f32 in HBM/LDS, split in
+//         registers; weights pre-split on the host into [Cout][K/32][32 p0 | 32 p1 | 32 p2] bf16 and staged as three plane sub-tiles.
 template <int BM, int BN, int WM, int WN, int PREC>
 __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
     constexpr int NW = WM * WN;
