@@ -360,3 +360,27 @@ def test_lora_adapter_directory_is_parsed_merged_and_unloaded(tmp_path):
         lora.adapter_factors({"base_model.model.blocks.0.cross_attn.q.lora_A.weight": fac["blocks.0.cross_attn.q"][0]})
     for n in tgt:
         assert torch.equal(dict(m.named_modules())[n].weight, base[n]), "failed loads must leave the model untouched"
+
+
+def test_vae_pass_length_falls_back_when_memory_runs_out():
+    """WanVAE_._with_pass_length: an out-of-memory error at `frames_per_pass` frames retries with half the pass length down to the
+    reference's 1 (the result does not depend on it); at 1 the error propagates."""
+    import types
+    m = WanVAE_(dim=32, dec_dim=32, z_dim=48, dim_mult=(1, 2, 4, 4), temperal_downsample=(False, True, True))
+    m._engine = types.SimpleNamespace(scratch={"k": 1})
+    m.frames_per_pass = 8
+    seen = []
+
+    def body(G, tag):
+        seen.append(G)
+        if G > 2:
+            raise torch.cuda.OutOfMemoryError("simulated")
+        return (tag, G)
+
+    assert m._with_pass_length(body, "x") == ("x", 2) and seen == [8, 4, 2] and m._engine.scratch == {}
+
+    def always(G):
+        raise torch.cuda.OutOfMemoryError("simulated")
+
+    with pytest.raises(torch.cuda.OutOfMemoryError):
+        m._with_pass_length(always)

@@ -454,14 +454,32 @@ class WanVAE_(nn.Module):
         if self._engine is not None:
             self._engine.reset()
 
+    def _with_pass_length(self, body, *args):
+        """Runs encode / decode at `frames_per_pass`; if the device runs out of memory, again with half the pass length (down to the
+        reference's 1): the result does not depend on it, only the size of the intermediate tensors does."""
+        G = max(1, int(self.frames_per_pass))
+        while True:
+            try:
+                return body(G, *args)
+            except torch.cuda.OutOfMemoryError:
+                if G == 1:
+                    raise
+                logging.warning(f"WanVAE_: out of memory at {G} frames per pass, retrying with {G // 2}")
+                G //= 2
+                self._engine.scratch.clear()
+                torch.cuda.empty_cache()
+
     def encode(self, x, scale):
         """WanVAE_.encode vae2_2.py:783-810: x [1, 3, F, H, W] fp32 -> [1, z, (F-1)//4+1, H/16, W/16]."""
+        return self._with_pass_length(self._encode, x, scale)
+
+    def _encode(self, G, x, scale):
         eng = self._eng()
         eng.reset()
         vid = x[0].contiguous().float()
         F = vid.shape[1]
         outs = [eng.encoder_chunk(vid, 0, 1, first_chunk=True)]
-        n4, G = (F - 1) // 4, max(1, int(self.frames_per_pass))                  # 4-frame chunks after the first frame
+        n4 = (F - 1) // 4                                                         # 4-frame chunks after the first frame
         for c0 in range(0, n4, G):
             g = min(G, n4 - c0)
             outs.append(eng.encoder_chunk(vid, 1 + 4 * c0, 4 * g, first_chunk=False))
@@ -476,6 +494,9 @@ class WanVAE_(nn.Module):
 
     def decode(self, z, scale, clamp=True):
         """WanVAE_.decode vae2_2.py:812-839 (+ the wrapper's clamp :1045): z [1, z, f, h, w] -> [1, 3, 4(f-1)+1, 16h, 16w]."""
+        return self._with_pass_length(self._decode, z, scale)
+
+    def _decode(self, G, z, scale):
         eng = self._eng()
         eng.reset()
         zz = z[0].contiguous().float()
@@ -487,7 +508,6 @@ class WanVAE_(nn.Module):
         F = 4 * (f - 1) + 1
         vid = torch.empty(1, 3, F, 16 * h, 16 * w, dtype=torch.float32, device=zz.device)
         f0 = 0
-        G = max(1, int(self.frames_per_pass))
         for i0, i1 in [(0, 1)] + [(i, min(i + G, f)) for i in range(1, f, G)]:
             y = eng.decoder_chunk(x[i0:i1], first_chunk=(i0 == 0))               # [T, 8h, 8w, 12]
             T = y.shape[0]
