@@ -109,20 +109,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
     // are computed up front, and staging a k-tile costs a bit test, a select against the zero page and a 64-bit add per piece -
     // instead of re-deriving (t, h, w), three bounds checks and a 64-bit multiply-add behind an exec-mask branch, per piece and
     // k-tile (the compiled loop spent ~150 VALU / SALU instructions and 4 divergent branches there per 128 MFMAs).
-    const bool fast = !p.up && p.kt * p.kh * p.kw <= 32;
+    // The 2x-upsampling convolutions (nearest-exact upsample folded into the gather: source pixel = upsampled coordinate >> 1) use
+    // the same scheme with one more per-piece fact: the source offset of tap dh is ((oh + dh - ph) >> 1) - ((oh - ph) >> 1) rows,
+    // which depends on the parity of the piece's own upsampled row (and column) only: (dh + par_h) >> 1.
+    const bool fast = p.kt * p.kh * p.kw <= 32;
     const float* a_base[A_INSTR];
     unsigned a_mask[A_INSTR];
+    int a_par[A_INSTR];              // up: bit 0 = parity of the upsampled row of tap 0, bit 1 = of its column
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         const int it0 = a_t[i] * p.st + p.t_off, ih0 = a_h[i] * p.sh - p.ph, iw0 = a_w[i] * p.sw - p.pw;
-        a_base[i] = p.in + (long)it0 * frame + ((long)ih0 * p.Win + iw0) * p.ld_in + a_c[i];
+        // (arithmetic shift: ih0 = -1 -> source row -1, whose taps are masked off below)
+        const int sh0 = p.up ? ih0 >> 1 : ih0, sw0 = p.up ? iw0 >> 1 : iw0;
+        a_par[i] = p.up ? ((ih0 & 1) | ((iw0 & 1) << 1)) : 0;
+        a_base[i] = p.in + (long)it0 * frame + ((long)sh0 * p.Win + sw0) * p.ld_in + a_c[i];
         unsigned mk = 0;
         if (fast) {
             for (int dt = 0, tap = 0; dt < p.kt; ++dt)
                 for (int dh = 0; dh < p.kh; ++dh)
                     for (int dw = 0; dw < p.kw; ++dw, ++tap) {
-                        const bool ok = (unsigned)(it0 + dt) < (unsigned)p.Tin && (unsigned)(ih0 + dh) < (unsigned)p.Hin &&
-                                        (unsigned)(iw0 + dw) < (unsigned)p.Win;
+                        const bool ok = (unsigned)(it0 + dt) < (unsigned)p.Tin && (unsigned)(ih0 + dh) < (unsigned)Hlim &&
+                                        (unsigned)(iw0 + dw) < (unsigned)Wlim;
                         mk |= (unsigned)ok << tap;
                     }
         }
@@ -135,9 +142,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
 #define UV_CONV_STAGE(KT, BUF)                                                                                        \
     do {                                                                                                              \
         char* sbase = smem + (BUF) * STAGE;                                                                           \
-        if (fast) {                                                                                                   \
+        if (fast && !p.up) {                                                                                          \
             _Pragma("unroll") for (int i = 0; i < A_INSTR; ++i) {                                                     \
                 const float* src = ((a_mask[i] >> s_tap) & 1u) ? a_base[i] + (s_off + s_ci) : p.zeros;                \
+                __builtin_amdgcn_global_load_lds(src, (lds_void_c*)(sbase + (i * NW + wave) * 1024), 16, 0, 0);       \
+            }                                                                                                         \
+        } else if (fast) {                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < A_INSTR; ++i) {                                                     \
+                const int rh = (s_dh + (a_par[i] & 1)) >> 1, rw = (s_dw + (a_par[i] >> 1)) >> 1;                      \
+                const long off = (long)s_dt * frame + (long)(rh * p.Win + rw) * p.ld_in + s_ci;                       \
+                const float* src = ((a_mask[i] >> s_tap) & 1u) ? a_base[i] + off : p.zeros;                           \
                 __builtin_amdgcn_global_load_lds(src, (lds_void_c*)(sbase + (i * NW + wave) * 1024), 16, 0, 0);       \
             }                                                                                                         \
         } else {                                                                                                      \
