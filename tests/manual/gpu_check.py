@@ -7,7 +7,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from univid_amd import _lib  # noqa: E402
 from univid_amd._lib import *  # noqa: E402,F401,F403
 
@@ -116,7 +116,6 @@ def check_attn():
 
 def check_glue():
     print("== glue")
-    sys.path.insert(0, "/root/repo")
     from oracle import wan_dit
     L, C, D = 70, 3072, 128
     x = torch.randn(L, C) * 2 + 0.3

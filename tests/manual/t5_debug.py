@@ -1,5 +1,5 @@
-import sys, torch, math
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os, sys, torch, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from univid_amd import _lib
 from conftest import load_golden
 from oracle import t5 as ot5

@@ -1,8 +1,8 @@
 """Full-RESOLUTION VAE parity (BASELINE config 4, 720 x 1280): HIP encode / decode of an F-frame clip against the oracle's text executed by
 torch-ROCm eager on the same GPU (MIOpen fp32 convolutions). Minutes of MIOpen kernel search on a fresh box - a tool, not a test; the
-round's output is profiles/r02_vae_fullres_vs_eager.log.   F=5 python3 tools/vae_fullres_check.py"""
+round's output is profiles/r02_vae_fullres_vs_eager.log.   F=5 python3 tests/manual/vae_fullres_check.py"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import wan_vae
 from univid_amd.wan.vae2_2 import Wan2_2_VAE
 dev = "cuda"
