@@ -49,11 +49,21 @@ def test_no_fallback_without_gpu():
 def test_product_does_not_import_oracle():
     """Only tests/, smoke and bench's cpu_baseline may touch oracle/."""
     bad = []
-    for dp, _, files in os.walk(os.path.join(ROOT, "univid_amd")):
-        for f in files:
-            if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dp, f)).read(), flags=re.M):
-                bad.append(f)
+    for top in ("univid_amd", "tools"):
+        for dp, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dp, f)).read(), flags=re.M):
+                    bad.append(os.path.join(top, f))
     assert not bad, bad
+    # bench.py: the oracle appears only inside the cpu_baseline functions; __graft_entry__: inside smoke(), and build() checks that it imports
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+        head = src[:m.start()]
+        fn = re.findall(r"^def (\w+)", head, flags=re.M)[-1]
+        assert fn.startswith("cpu_baseline"), f"bench.py imports the oracle inside {fn}()"
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    for m in re.finditer(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+        assert re.findall(r"^def (\w+)", src[:m.start()], flags=re.M)[-1] in ("smoke", "build")   # build() only imports the checker
 
 
 def test_detinit_is_deterministic_and_device_independent():
