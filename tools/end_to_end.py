@@ -1,0 +1,42 @@
+"""End-to-end generation time at the bench size (developer tool): WanTI2V.t2v / i2v with the production model sizes (30-block TI2V-5B
+DiT, full-width VAE, random-init weights, synthetic prompt embeddings): 50 UniPC steps with CFG + VAE decode of the 49-frame 704x1280
+clip, per stage, for the exact-f32 VAE and the f32-grade bf16x6 mode."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from univid_amd import _lib
+from univid_amd.wan.model import WanModel
+from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+from univid_amd.wan.vae2_2 import Wan2_2_VAE
+_lib.init()
+dev = "cuda"
+steps = int(os.environ.get("STEPS", 50))
+with torch.device(dev):
+    m = WanModel.from_config(TI2VConfig.dit)
+m = m.eval().requires_grad_(False)
+m.init_weights(0)
+m.prepare()
+g = torch.Generator(device=dev).manual_seed(1)
+pe = [torch.randn(40, 4096, device=dev, generator=g) * 0.1]
+ne = [torch.randn(9, 4096, device=dev, generator=g) * 0.1]
+
+
+def clock(fn):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+    return r, time.perf_counter() - t0
+
+
+for prec in ("fp32", "bf16x6"):
+    vae = Wan2_2_VAE(device=dev, seed=0, precision=prec)
+    pipe = WanTI2V(model=m, vae=vae, device=dev)
+    with torch.no_grad():
+        pipe.t2v("", size=(1280, 704), frame_num=49, sampling_steps=2, seed=7, prompt_embeds=pe, negative_prompt_embeds=ne)   # warm-up
+        lat, t_den = clock(lambda: pipe.t2v("", size=(1280, 704), frame_num=49, sampling_steps=steps, seed=7, prompt_embeds=pe,
+                                            negative_prompt_embeds=ne, decode=False))
+        vid, t_dec = clock(lambda: vae.decode([lat])[0])
+        img = vid[:, 0].clamp(-1, 1).contiguous()
+        _, t_i2v = clock(lambda: pipe.i2v("", img, max_area=704 * 1280, frame_num=49, sampling_steps=steps, seed=3, prompt_embeds=pe,
+                                          negative_prompt_embeds=ne))
+    print(f"VAE {prec:7s}: t2v {steps} steps {t_den:6.2f} s ({t_den / steps * 1e3:.1f} ms/step) + decode {t_dec:5.2f} s = {t_den + t_dec:6.2f} s per "
+          f"49-frame 704x1280 clip; i2v (encode 1 frame + {steps} steps + decode) {t_i2v:6.2f} s; finite {bool(torch.isfinite(vid).all())}", flush=True)
+    del vae, pipe
+    torch.cuda.empty_cache()
