@@ -33,6 +33,9 @@ SHAPES = [
     ("aligned q (89 x 256 rows)", 22784, 3072, 3072, EPI_BF16),
     ("aligned ffn.0 shape", 22784, 14336, 3072, EPI_BF16),
     ("aligned ffn.2 shape", 22784, 3072, 14336, EPI_BF16),
+    ("ranker q/k/v/o (64 x 256 tokens)", 16384, 768, 768, EPI_BF16),
+    ("ranker fc1", 16384, 3072, 768, EPI_GELU_BF16),
+    ("ranker fc2", 16384, 768, 3072, EPI_BF16),
 ]
 
 

@@ -1087,6 +1087,11 @@ static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStrea
     switch (tile_cfg) {
         case 0: {  // default (only reached for shapes the split/ping-pong path in uv_gemm_bf16_nt does not take)
             if (M < 2048 || N < 1024) {
+                // tall and narrow (the SigLIP2 towers: 16 384 x 768): 256x256 tiles on the ping-pong kernel beat 128x128 tiles even
+                // at 3/4 of a round of workgroups (q / k / v / o 33.7 -> 30.1 us, fc2 with K = 3072 89.7 -> 71.9 us)
+                if (M >= 4096 && N >= 512 && N % 256 == 0 && K % 128 == 0 && K >= 256 && a.ldo % 8 == 0 && a.M % 256 == 0 &&
+                    2L * (M / 256) * (N / 256) >= num_cus())
+                    return launch_8ph<5, F16>(a, epilogue, s);
                 // few tiles (at most ~2 per CU): 8 waves on a 4-stage ring hide the DMA/LDS latency that one 4-wave
                 // workgroup per CU leaves exposed; many tiles: 4-wave workgroups, 2-3 resident per CU
                 const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
