@@ -293,7 +293,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
+    # the loop owns its (loop-constant) context tensors, as WanTI2V.denoise does: step-constant context work once per context
+    with torch.no_grad(), model.context_cached():
         for i in range(args.warmup):
             latent = one_step(i, latent)
         # live HIP-event timing of the dominant kernel (self-attention) on the launch stream

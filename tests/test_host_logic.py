@@ -368,8 +368,49 @@ def test_lora_adapter_directory_is_parsed_merged_and_unloaded(tmp_path):
         lora.merge_adapter_(m, {"blocks.0.norm3": fac["blocks.0.cross_attn.q"]}, dict(r=r, lora_alpha=8))
     with pytest.raises(ValueError):
         lora.adapter_factors({"base_model.model.blocks.0.cross_attn.q.lora_A.weight": fac["blocks.0.cross_attn.q"][0]})
+    # no config file / no lora_alpha / per-module patterns: the scaling cannot be guessed (peft refuses too; its default alpha is 8, not r)
+    nocfg = tmp_path / "nocfg"
+    write(nocfg, ".default", "lora_weights.pt")
+    (nocfg / "adapter_config.json").unlink()
+    with pytest.raises(ValueError, match="lora_alpha"):
+        lora.LoRAManager().load_lora_weights(str(nocfg), m)
+    with pytest.raises(ValueError, match="lora_alpha"):
+        lora.merge_adapter_(m, fac, dict(r=r))
+    with pytest.raises(NotImplementedError, match="rank_pattern"):
+        lora.LoRAManager().load_lora_weights(write(tmp_path / "rp", "", "safetensors", rank_pattern={"blocks.0.cross_attn.q": 8}), m)
+    with pytest.raises(NotImplementedError, match="alpha_pattern"):
+        lora.LoRAManager().load_lora_weights(write(tmp_path / "ap", "", "safetensors", alpha_pattern={"blocks.1.ffn.0": 32}), m)
+    # an error on the LAST module must not leave the first ones merged (validation precedes mutation)
+    with pytest.raises(KeyError):
+        lora.merge_adapter_(m, {**fac, "blocks.0.norm3": fac["blocks.0.cross_attn.q"]}, dict(r=r, lora_alpha=8))
     for n in tgt:
         assert torch.equal(dict(m.named_modules())[n].weight, base[n]), "failed loads must leave the model untouched"
+
+
+def test_context_cache_is_scoped_and_survives_inference_tensors():
+    """the context cache keys on tensor identity + version counter, so it is OFF for the bare reference-signature forward and
+    switched on only inside `context_cached()` (WanTI2V.denoise, bench.py); tensors made under torch.inference_mode() have no version
+    counter and must not crash the key; the graph key uses a monotonic prepared-weights generation, not id()."""
+    from oracle import wan_dit
+    from univid_amd.wan.model import tensor_version
+    m = WanModel.from_config(dict(wan_dit.TINY_CFG, model_type="ti2v"))
+    assert m.cache_context is False
+    with m.context_cached():
+        assert m.cache_context is True
+        with m.context_cached():
+            assert m.cache_context is True
+        assert m.cache_context is True, "the inner scope must not switch the outer one off"
+    assert m.cache_context is False and m._ctx_cache is None
+    with pytest.raises(ZeroDivisionError):
+        with m.context_cached():
+            1 / 0
+    assert m.cache_context is False, "the scope must end on an exception too"
+    with torch.inference_mode():
+        u = torch.zeros(3)
+    assert tensor_version(u) == -1 and tensor_version(torch.zeros(3)) == 0
+    g0 = m._prep_gen
+    m.invalidate()
+    assert m._prep_gen == g0 + 1
 
 
 def test_vae_pass_length_falls_back_when_memory_runs_out():

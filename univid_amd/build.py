@@ -20,6 +20,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-va
          "-ffp-contract=off"]
 
 
+# per-file additions. attn_pw4.hip: its slots are hand-placed scalar f32 operations beside MFMAs; SLP-packing them into v_pk_*_f32
+# costs issue cycles there (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+FILE_FLAGS = {"attn_pw4.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -29,6 +34,10 @@ def _hipcc():
 
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
 
 
 _TOOL = None
@@ -47,7 +56,7 @@ def _toolchain_id():
 
 def _digest(path, extra=""):
     h = hashlib.sha256()
-    for p in [path, os.path.join(CSRC, "common.h")]:
+    for p in [path, *headers()]:
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
@@ -57,23 +66,24 @@ def _digest(path, extra=""):
 
 
 def source_id():
-    """Digest of every kernel source + common.h + flags (NOT the toolchain: the GPU box may not have the same hipcc banner and
+    """Digest of every kernel source + header + flags (NOT the toolchain: the GPU box may not have the same hipcc banner and
     only checks that the .so it received belongs to the sources it received). Compiled into the library as uv_build_id();
     univid_amd._lib.load() compares the two, so a stale .so next to newer sources fails loudly instead of running old kernels
     behind new ctypes signatures."""
     h = hashlib.sha256()
-    for p in sources() + [os.path.join(CSRC, "common.h")]:
+    for p in sources() + headers():
         h.update(os.path.basename(p).encode())
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()[:24]
 
 
 def _compile(src):
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
     stamp = obj + ".sha"        # lives next to the object it describes; both are git-ignored
-    extra = []
+    extra = list(FILE_FLAGS.get(os.path.basename(src), []))
     if os.path.basename(src) == "capi.hip":
         extra = [f'-DUV_BUILD_ID="{source_id()}"']
     dig = _digest(src, " ".join(extra))

@@ -28,31 +28,14 @@
 //   * the softmax reference maximum moves only when a row maximum outgrows it by more than 2^UV_ATT_DEFER.
 //   * independent samples are one launch: q/k/out rows and V^T COLUMNS stacked per sample.
 // Template parameters of flash_attn_fwd_kernel: D head_dim (128 / 64), SGB fragment reads scheduled 6 ahead of their MFMA, F16 IEEE fp16 operands.
-#include "common.h"
+#include "attn_args.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
-#define UV_ATT_QW 32     // queries per wave
-#define UV_ATT_KV 64
-#define UV_ATT_DEFER 8.0f   // log2 of the largest P allowed before the reference maximum is moved
-
-struct AttnArgs {
-    const bf16_t* q;   // [Lq, ldq]   head h at column h*128
-    const bf16_t* k;   // [Lk, ldk]
-    const bf16_t* vt;  // [H*128, ldvt]  (V transposed; ldvt >= roundup(Lk, 64), pad finite)
-    bf16_t* out;       // [Lq, ldo]
-    long ldq, ldk, ldvt, ldo;
-    int Lq, Lk, H, q_blocks, batch;
-    int n12;           // flash_attn_fwd12_kernel: query blocks per head that own 12 units; the other q_blocks - n12 own 8
-    float scale_log2;  // softmax_scale * log2(e)
-};
+#define UV_ATTN_LONG_DEFAULT_PW4 false
 
 typedef __attribute__((address_space(3))) void lds_void_a;
-
-__device__ __forceinline__ int perm23(int i) {  // swap bits 2 and 3
-    return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
-}
 
 // D = head_dim (128 for TI2V-5B; 64 for the reference's CPU-runnable tiny config and the SigLIP2 ranker).
 // 4 waves x 32 queries per workgroup, 2 workgroups per CU: the two waves that share a SIMD then belong to DIFFERENT workgroups, are
@@ -917,9 +900,18 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // ---- kernel selection: the ONE place that decides which kernel serves a call ------------------------------------------------
-enum AttnKernel { ATT_FWD12 = 0, ATT_FWD3 = 1, ATT_FWD_D128 = 2, ATT_FWD_D64 = 3 };
+enum AttnKernel { ATT_FWD12 = 0, ATT_FWD3 = 1, ATT_FWD_D128 = 2, ATT_FWD_D64 = 3, ATT_PW4 = 4 };
 static const char* const kAttnKernelName[] = {"flash_attn_fwd12_kernel", "flash_attn_fwd3_kernel", "flash_attn_fwd_kernel<128>",
-                                              "flash_attn_fwd_kernel<64>"};
+                                              "flash_attn_fwd_kernel<64>", "flash_attn_pw4_kernel"};
+
+// Which kernel serves long key sequences: UV_ATTN_LONG=fwd12 | pw4 in the environment (read per call; developer A/B knob for
+// tools/attn_bench.py - both kernels produce bit-identical output), default below.
+static bool attn_long_pw4() {
+    const char* e = getenv("UV_ATTN_LONG");
+    if (e && e[0] == 'f') return false;
+    if (e && e[0] == 'p') return true;
+    return UV_ATTN_LONG_DEFAULT_PW4;
+}
 
 static AttnKernel attn_select(int Lk, int head_dim, long ldk, long ldvt, bool f16) {
     if (head_dim != 128) return ATT_FWD_D64;
@@ -928,7 +920,8 @@ static AttnKernel attn_select(int Lk, int head_dim, long ldk, long ldvt, bool f1
     // long key sequences: one 12-wave workgroup per CU shares each K / V^T tile among up to 384 queries (a third of the L2 -> LDS
     // traffic; -2.8 % on the self-attention launches); short ones (cross-attention, Lk = 512: prologue and last round weigh
     // more) keep the 4-wave workgroups (the 12-wave form is 24 % slower there)
-    return Lk >= 2048 ? ATT_FWD12 : ATT_FWD3;
+    if (Lk < 2048) return ATT_FWD3;
+    return attn_long_pw4() ? ATT_PW4 : ATT_FWD12;
 }
 
 // Cut of a (sample, head)'s NWU = ceil(Lq / 32) query units into n12 blocks of 12 units followed by n8 blocks of 8 units for
@@ -938,8 +931,14 @@ static AttnKernel attn_select(int Lk, int head_dim, long ldk, long ldvt, bool f1
 // 30 + 0; mixes with more 8-unit blocks lose (24 + 9: 3.03 ms). At batch 1 the model picks 30 + 0 (768 workgroups = 3 rounds).
 static void attn12_cut(int Lq, int heads_total, int* n12_out, int* n8_out) {
     const int nwu = (Lq + UV_ATT_QW - 1) / UV_ATT_QW, ncu = uv_num_cus();
-    static int memo_key[2] = {0, 0}, memo_val[2] = {0, 0};
-    if (memo_key[0] == nwu && memo_key[1] == heads_total * 1024 + ncu) { *n12_out = memo_val[0]; *n8_out = memo_val[1]; return; }
+    // small per-thread memo (ctypes releases the GIL: two host threads, one per GPU, may be in here with different shapes at once;
+    // alternating shapes must not re-run the list-scheduling scan, ~ blocks x CUs x cuts host operations, on every call)
+    struct Memo { int nwu, key, n12, n8; };
+    static thread_local Memo memo[8];
+    static thread_local int memo_next = 0;
+    const int mkey = heads_total * 1024 + ncu;
+    for (const Memo& e : memo)
+        if (e.nwu == nwu && e.key == mkey) { *n12_out = e.n12; *n8_out = e.n8; return; }
     const double T8 = 0.76;   // measured: all-8-unit cut 0.365 ms per round of workgroups, all-12-unit cut 0.48 ms (batch 2, L = 11 440)
     int best12 = (nwu + 11) / 12, best8 = 0;
     double best = 1e30;
@@ -964,7 +963,8 @@ static void attn12_cut(int Lq, int heads_total, int* n12_out, int* n8_out) {
         for (int i = 0; i < m; ++i) mk = load[i] > mk ? load[i] : mk;
         if (mk < best - 1e-9) { best = mk; best12 = n12; best8 = n8; }
     }
-    memo_key[0] = nwu; memo_key[1] = heads_total * 1024 + ncu; memo_val[0] = best12; memo_val[1] = best8;
+    memo[memo_next] = Memo{nwu, mkey, best12, best8};
+    memo_next = (memo_next + 1) & 7;
     *n12_out = best12; *n8_out = best8;
 }
 
@@ -1002,6 +1002,9 @@ static int attn_entry(const char* name, const void* q, long ldq, const void* k, 
                 a.q_blocks = n12 + n8;
             }
             hipLaunchKernelGGL((flash_attn_fwd12_kernel<3, true>), dim3(a.q_blocks * H * batch), dim3(768), 0, st, a);
+            break;
+        case ATT_PW4:
+            uv_launch_attn_pw4(a, st);
             break;
         case ATT_FWD3:
             a.q_blocks = (Lq + 127) / 128;

@@ -75,8 +75,16 @@ def adapter_factors(tensors: Dict[str, torch.Tensor]) -> Dict[str, Tuple[torch.T
 
 
 def adapter_scaling(cfg: dict, r: int) -> float:
-    """peft LoraLayer.update_layer: lora_alpha / r, or lora_alpha / sqrt(r) with use_rslora."""
-    alpha = cfg.get("lora_alpha", cfg.get("alpha", r))
+    """peft LoraLayer.update_layer: lora_alpha / r, or lora_alpha / sqrt(r) with use_rslora. The config MUST name lora_alpha: PEFT
+    refuses an adapter directory without its config, and guessing alpha (= r, scaling 1) folds the adapter in at the wrong strength."""
+    if "lora_alpha" not in cfg and "alpha" not in cfg:
+        raise ValueError("the adapter's config (adapter_config.json / lora_config.json) is missing or does not name lora_alpha: "
+                         "the merge scaling lora_alpha / r cannot be guessed")
+    for pat in ("rank_pattern", "alpha_pattern"):
+        if cfg.get(pat):
+            raise NotImplementedError(f"adapter config has a non-empty {pat} (per-module rank / alpha): one global scaling would merge "
+                                      f"those modules at the wrong strength")
+    alpha = cfg.get("lora_alpha", cfg.get("alpha"))
     return alpha / math.sqrt(r) if cfg.get("use_rslora", False) else alpha / r
 
 
@@ -89,13 +97,17 @@ def merge_adapter_(model: nn.Module, factors, cfg: dict):
         raise NotImplementedError(f"LoRA bias mode {cfg.get('bias')!r} is not supported (the reference uses 'none')")
     mods = dict(model.named_modules())
     saved = {}
+    # validate EVERY (module, shape, scaling) before the first weight is touched: an error must not leave a half-merged model
+    for name, (a, b) in factors.items():
+        lin = mods.get(name)
+        if not isinstance(lin, nn.Linear):
+            raise KeyError(f"adapter targets {name!r}, which is not an nn.Linear of this model")
+        if tuple(lin.weight.shape) != (b.shape[0], a.shape[1]):
+            raise ValueError(f"adapter for {name!r} is {b.shape[0]} x {a.shape[1]}, the layer is {tuple(lin.weight.shape)}")
+        adapter_scaling(cfg, a.shape[0])
     with torch.no_grad():
         for name, (a, b) in factors.items():
-            lin = mods.get(name)
-            if not isinstance(lin, nn.Linear):
-                raise KeyError(f"adapter targets {name!r}, which is not an nn.Linear of this model")
-            if tuple(lin.weight.shape) != (b.shape[0], a.shape[1]):
-                raise ValueError(f"adapter for {name!r} is {b.shape[0]} x {a.shape[1]}, the layer is {tuple(lin.weight.shape)}")
+            lin = mods[name]
             w = lin.weight
             delta = (b.to(w.device, torch.float32) @ a.to(w.device, torch.float32)) * adapter_scaling(cfg, a.shape[0])
             if cfg.get("fan_in_fan_out", False):

@@ -19,6 +19,7 @@ the reference's [L, 6, dim] fp32 modulation tensor (843 MB at L = 11 440): the d
 (1 for t2v, 2 for i2v) go through the time MLPs once, and kernels index the resulting rows with a
 token -> row map.
 """
+import contextlib
 import math
 from typing import List, Optional
 
@@ -383,6 +384,15 @@ def _vt_scratch(tag, C, batch, L, device):
     return t
 
 
+def tensor_version(u):
+    """`u._version`, or -1 for a tensor created under torch.inference_mode() (no version counter; such a tensor cannot be written
+    in place outside inference mode, and inside a `context_cached()` scope the caller vouches for it)."""
+    try:
+        return u._version
+    except RuntimeError:
+        return -1
+
+
 def _ensure_prepared(mod):
     if getattr(mod, "_prep", None) is None:
         mod.prepare()
@@ -441,7 +451,12 @@ class WanModel(nn.Module):
         self._prep = None
         self._ctx_cache = None   # (key, input tensors kept alive, embedded contexts, generation): see _embedded_context
         self._ctx_gen = 0
-        self.cache_context = True   # step-constant context work (text_embedding, cross-attention K / V^T) is computed once per context
+        self._prep_gen = 0       # bumped by prepare() and invalidate(): the identity of "the prepared weights" for cache / graph keys
+        # Step-constant context work (text_embedding, cross-attention K / V^T) computed once per context. OFF for the bare
+        # reference-signature forward: the cache key is tensor identity + version counter, which cannot see writes that bypass the
+        # counter (`.data` writes, raw-pointer kernels). A sampling loop that OWNS its context tensors for its duration switches it
+        # on around the loop: `with model.context_cached(): ...` (WanTI2V.denoise and bench.py do).
+        self.cache_context = False
         self.sp = None   # SeqParallel when Ulysses sequence parallelism is enabled (enable_sequence_parallel)
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
 
@@ -449,6 +464,7 @@ class WanModel(nn.Module):
     def invalidate(self):
         """Forget the bf16 weight copies (call after changing parameters in place)."""
         self._prep = None
+        self._prep_gen += 1
         self._ctx_cache = None
         for b in self.blocks:
             b._prep = None
@@ -466,6 +482,7 @@ class WanModel(nn.Module):
         pe = nn.Linear(1, 1, bias=True)
         pe.weight = nn.Parameter(self.patch_embedding.weight.detach().flatten(1), requires_grad=False)
         pe.bias = nn.Parameter(self.patch_embedding.bias.detach(), requires_grad=False)
+        self._prep_gen += 1
         self._prep = {
             "patch": _Prepared(pe, pad_k=64),
             "text0": _Prepared(self.text_embedding[0], pad_k=64),
@@ -514,6 +531,22 @@ class WanModel(nn.Module):
             outs.append(c)
         return torch.stack(outs)
 
+    @contextlib.contextmanager
+    def context_cached(self):
+        """Scope in which the caller guarantees that the context tensors it passes are not written behind the version counter
+        (a sampling loop over loop-constant prompt embeddings): text_embedding and the blocks' cross-attention K / V^T are then
+        computed once per context. The cache is dropped when the outermost scope ends."""
+        prev = self.cache_context
+        self.cache_context = True
+        try:
+            yield self
+        finally:
+            self.cache_context = prev
+            if not prev:
+                self._ctx_cache = None
+                for b in self.blocks:
+                    b.cross_attn._kv_cache = {}
+
     def _embedded_context(self, context):
         """text_embedding of the prompt embeddings, cached across forwards: in a sampling loop the same context tensors come
         back every step (textimage2video.py:380-385), and neither text_embedding (model.py:472-478) nor the blocks'
@@ -523,7 +556,7 @@ class WanModel(nn.Module):
         Returns (embedded contexts [B, text_len, C] bf16, generation id or None when caching is off)."""
         if not self.cache_context:
             return self.embed_context(context), None
-        key = tuple((u.data_ptr(), u._version, tuple(u.shape), u.dtype, u.device) for u in context)
+        key = tuple((u.data_ptr(), tensor_version(u), tuple(u.shape), u.dtype, u.device) for u in context)
         c = self._ctx_cache
         if c is None or c[0] != key:
             self._ctx_gen += 1

@@ -10,6 +10,7 @@ i2v :413-619) with the same method names, keyword arguments and defaults. Differ
     (288 GB HBM: nothing is ever moved to the host).
   * generation errors raise instead of being swallowed.
 """
+import contextlib
 import math
 import random
 import sys
@@ -19,7 +20,7 @@ import torch
 
 from .fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
 from .fm_solvers_unipc import FlowUniPCMultistepScheduler
-from .model import WanModel
+from .model import WanModel, _ensure_prepared, tensor_version
 
 
 def masks_like(tensor, zero=False, generator=None, p=0.2):
@@ -212,6 +213,13 @@ class WanTI2V:
     # ---- the hot loop ----------------------------------------------------------------------------------------
     def denoise(self, noise, context, context_null, sampling_steps, shift, guide_scale, z=None, record=None, graph=None,
                 sample_solver="unipc"):
+        # the loop owns its context tensors for its duration: step-constant context work is computed once (WanModel.context_cached)
+        cached = self.model.context_cached() if hasattr(self.model, "context_cached") else contextlib.nullcontext()
+        with cached:
+            return self._denoise(noise, context, context_null, sampling_steps, shift, guide_scale, z, record, graph, sample_solver)
+
+    def _denoise(self, noise, context, context_null, sampling_steps, shift, guide_scale, z=None, record=None, graph=None,
+                 sample_solver="unipc"):
         """Steps of t2v (:356-394) / i2v (:548-601) on a given noise latent [C, f, h, w] (fp32, on device).
 
         z: first-frame latent [C, 1, h, w] switches on the i2v masking (mask2 zero on frame 0, :550-551, :598).
@@ -255,8 +263,9 @@ class WanTI2V:
         runner = None
         if graph:
             # one captured graph per (latent shape, mode, contexts, prepared weights): generations that repeat them replay it
-            key = (tuple(latent.shape), i2v, tuple((u.data_ptr(), u._version) for u in list(context) + list(context_null)),
-                   id(self.model._prep))
+            _ensure_prepared(self.model)
+            key = (tuple(latent.shape), i2v, tuple((u.data_ptr(), tensor_version(u)) for u in list(context) + list(context_null)),
+                   self.model._prep_gen)
             runner = self._runner if (self._runner is not None and self._runner.key == key and
                                       self._runner.gen == self.model._ctx_gen) else None
             if runner is None:
