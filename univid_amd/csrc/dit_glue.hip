@@ -184,43 +184,32 @@ struct RmsRopeArgs {
 // One wave walks RPW consecutive token rows; the norm weight of its columns stays in registers. A lane's 8-element
 // chunks sit 512 columns apart, so when head_dim divides 512 they all map to the same 4 complex RoPE columns of a head:
 // the factors are fetched once per row instead of once per chunk.
-template <int MAXV, int RPW>
+// EXACT: C == MAXV * 512, every lane owns MAXV full chunks: no per-chunk predicates, so a row's loads are ONE burst behind ONE wait
+// (with the predicates hipcc branches around every chunk's load and waits vmcnt(0) chunk by chunk).
+template <int MAXV, int RPW, bool EXACT = false>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsRopeArgs p) {
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    // the wave index as a provably uniform value: the row, its RoPE position (three integer divisions) and the rope / no-rope branch
+    // then live on the scalar unit instead of costing vector instructions and registers in every lane
+    const int row0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RPW;
     if (row0 >= p.L) return;
     if (blockIdx.y == 1) { p.x = p.x2; p.out = p.out2; p.weight = p.weight2; }
-    const int nv = p.C >> 9;                     // 8-element chunks per lane (64 lanes * 8 = 512)
-    const int rem = (p.C & 511) >> 3;            // leftover chunks (C % 512 != 0, e.g. C = 256)
+    const int nv = EXACT ? MAXV : p.C >> 9;      // 8-element chunks per lane (64 lanes * 8 = 512)
+    const int rem = EXACT ? 0 : (p.C & 511) >> 3;   // leftover chunks (C % 512 != 0, e.g. C = 256)
     const int half = p.D >> 1;
-    const bool same_cols = (512 % p.D) == 0;
+    const bool same_cols = EXACT || (512 % p.D) == 0;      // EXACT launches require it: no per-chunk factor fetches, no branches
     f32x4 wv[MAXV][2];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
-        if ((i < nv) || (i == nv && lane < rem)) {
+        if (EXACT || (i < nv) || (i == nv && lane < rem)) {
             wv[i][0] = *(const f32x4*)(p.weight + (i * 64 + lane) * 8);
             wv[i][1] = *(const f32x4*)(p.weight + (i * 64 + lane) * 8 + 4);
         }
+    typedef __attribute__((ext_vector_type(2))) double f64x2;
     for (int rr = 0; rr < RPW; ++rr) {
         const int row = row0 + rr;
         if (row >= p.L) break;
         const bf16_t* xr = p.x + (long)row * p.ldx;
-        float v[MAXV][8];
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const bool on = (i < nv) || (i == nv && lane < rem);
-            if (on) {
-                const u32x4 raw = *(const u32x4*)(xr + (i * 64 + lane) * 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[i][2 * e] = bf2f((bf16_t)(raw[e] & 0xffff));
-                    v[i][2 * e + 1] = bf2f((bf16_t)(raw[e] >> 16));
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
-            }
-        }
         const int grow = row % p.Ls + p.row0;        // token index in its sample's whole sequence
         const bool do_rope = p.freqs != nullptr && grow < p.F * p.Hh * p.Ww;
         int pf = 0, ph = 0, pw = 0;
@@ -230,48 +219,78 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsRopeArgs p) {
             ph = t % p.Hh;
             pf = t / p.Hh;
         }
-        double fcr[4], fci[4];   // this lane's 4 complex factors (valid for every chunk when same_cols)
+        // this lane's 4 complex128 RoPE factors (valid for every chunk when same_cols): requested FIRST, as one burst with the row's
+        // chunks behind them (fetched one by one next to their conversion they were four dependent L2 round trips per row)
+        f64x2 fraw[4];
         if (do_rope && same_cols) {
             const int pair0 = ((lane * 8) % p.D) >> 1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ci = pair0 + e;
                 const int pos = ci < p.nf ? pf : (ci < p.nf + p.nh ? ph : pw);
-                const double* fr = p.freqs + ((long)pos * half + ci) * 2;
-                fcr[e] = fr[0];
-                fci[e] = fr[1];
+                fraw[e] = *(const f64x2*)(p.freqs + ((long)pos * half + ci) * 2);
             }
+        }
+        u32x4 raw[MAXV];                 // the row stays packed (bf16 pairs) between the two passes: half the registers of f32
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const bool on = EXACT || (i < nv) || (i == nv && lane < rem);
+            if (on) {
+                raw[i] = *(const u32x4*)(xr + (i * 64 + lane) * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = bf2f((bf16_t)(raw[i][e] & 0xffff)), hi = bf2f((bf16_t)(raw[i][e] >> 16));
+                    ss += lo * lo;
+                    ss += hi * hi;
+                }
+            }
+        }
+        // each double factor split into an f32 head and tail (cr = crh + crl to ~2^-49)
+        float fcrh[4], fcrl[4], fcih[4], fcil[4];
+        auto split_factor = [](const f64x2 f, float& rh, float& rl, float& ih, float& il) {
+            const double cr = f[0], ci = f[1];
+            rh = (float)cr; rl = (float)(cr - (double)rh);
+            ih = (float)ci; il = (float)(ci - (double)ih);
+        };
+        if (do_rope && same_cols) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_factor(fraw[e], fcrh[e], fcrl[e], fcih[e], fcil[e]);
         }
         const float mean = wave_sum(ss) / (float)p.C;
         const float rs = 1.0f / sqrtf(mean + p.eps);
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            const bool on = (i < nv) || (i == nv && lane < rem);
+            const bool on = EXACT || (i < nv) || (i == nv && lane < rem);
             if (on) {
                 const int c0 = (i * 64 + lane) * 8;
                 float y[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(round_bf(__fmul_rn(v[i][e], rs)), wv[i][e >> 2][e & 3]);
+                for (int e = 0; e < 8; ++e) {
+                    const float ve = bf2f((bf16_t)((e & 1) ? raw[i][e >> 1] >> 16 : raw[i][e >> 1] & 0xffff));
+                    y[e] = __fmul_rn(round_bf(__fmul_rn(ve, rs)), wv[i][e >> 2][e & 3]);
+                }
                 if (do_rope) {
                     const int pair0 = (c0 % p.D) >> 1;  // first complex index of this chunk inside its head
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        double cr, ci_;
+                        float rh, rl, ih, il;
                         if (same_cols) {
-                            cr = fcr[e];
-                            ci_ = fci[e];
+                            rh = fcrh[e]; rl = fcrl[e]; ih = fcih[e]; il = fcil[e];
                         } else {
                             const int ci = pair0 + e;
                             const int pos = ci < p.nf ? pf : (ci < p.nf + p.nh ? ph : pw);
-                            const double* fr = p.freqs + ((long)pos * half + ci) * 2;
-                            cr = fr[0];
-                            ci_ = fr[1];
+                            split_factor(*(const f64x2*)(p.freqs + ((long)pos * half + ci) * 2), rh, rl, ih, il);
                         }
-                        const double a = (double)y[2 * e], b = (double)y[2 * e + 1];
-                        const double re = __dsub_rn(__dmul_rn(a, cr), __dmul_rn(b, ci_));
-                        const double im = __dadd_rn(__dmul_rn(a, ci_), __dmul_rn(b, cr));
-                        y[2 * e] = (float)re;
-                        y[2 * e + 1] = (float)im;
+                        // (a + i b)(cr + i ci) of the reference's complex128 product, then .float(): evaluated in f32 with the factor
+                        // tails carried, innermost (smallest) terms first. a and b are f32 exactly; the two outer fused multiply-adds
+                        // round to f32 once each, so the result is within 1 f32 ulp of float(fp64 product) - the bf16 rounding that
+                        // follows sees a different value only when the exact result lies within 2^-16 of a bf16 rounding boundary
+                        // (~1e-5 of the elements; was: four f64 multiplies + two f64 adds + four conversions per pair, a third of
+                        // the kernel's time).
+                        const float a = y[2 * e], b = y[2 * e + 1];
+                        y[2 * e] = __builtin_fmaf(a, rh, __builtin_fmaf(-b, ih, __builtin_fmaf(a, rl, -__fmul_rn(b, il))));
+                        y[2 * e + 1] = __builtin_fmaf(a, ih, __builtin_fmaf(b, rh, __builtin_fmaf(a, il, __fmul_rn(b, rl))));
                     }
                 }
                 u32x4 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]), pack_bf2(y[4], y[5]), pack_bf2(y[6], y[7])};
@@ -301,13 +320,20 @@ static int rmsnorm_rope_launch(const char* name, const void* x, void* out, const
     const dim3 grid((L + 4 * rpw - 1) / (4 * rpw), x2 ? 2 : 1), block(256);
     const int chunks = (C + 511) / 512;
     hipStream_t st = (hipStream_t)stream;
+    // whole 512-column chunks and RoPE factors shared by a lane's chunks (or no RoPE): the predicate-free instantiations
+    const bool exact = C % 512 == 0 && (!freqs || 512 % head_dim == 0);
     if (rpw == 4) {
-        if (chunks <= 2) hipLaunchKernelGGL((rmsnorm_rope_kernel<2, 4>), grid, block, 0, st, a);
+        if (exact && chunks == 2) hipLaunchKernelGGL((rmsnorm_rope_kernel<2, 4, true>), grid, block, 0, st, a);
+        else if (exact && chunks == 6) hipLaunchKernelGGL((rmsnorm_rope_kernel<6, 4, true>), grid, block, 0, st, a);   // the DiT's 3072
+        else if (exact && chunks == 8) hipLaunchKernelGGL((rmsnorm_rope_kernel<8, 4, true>), grid, block, 0, st, a);   // umT5's 4096
+        else if (chunks <= 2) hipLaunchKernelGGL((rmsnorm_rope_kernel<2, 4>), grid, block, 0, st, a);
         else if (chunks <= 6) hipLaunchKernelGGL((rmsnorm_rope_kernel<6, 4>), grid, block, 0, st, a);
         else if (chunks <= 8) hipLaunchKernelGGL((rmsnorm_rope_kernel<8, 4>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((rmsnorm_rope_kernel<16, 4>), grid, block, 0, st, a);
     } else {
-        if (chunks <= 2) hipLaunchKernelGGL((rmsnorm_rope_kernel<2, 1>), grid, block, 0, st, a);
+        if (exact && chunks == 6) hipLaunchKernelGGL((rmsnorm_rope_kernel<6, 1, true>), grid, block, 0, st, a);
+        else if (exact && chunks == 8) hipLaunchKernelGGL((rmsnorm_rope_kernel<8, 1, true>), grid, block, 0, st, a);
+        else if (chunks <= 2) hipLaunchKernelGGL((rmsnorm_rope_kernel<2, 1>), grid, block, 0, st, a);
         else if (chunks <= 8) hipLaunchKernelGGL((rmsnorm_rope_kernel<8, 1>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((rmsnorm_rope_kernel<16, 1>), grid, block, 0, st, a);
     }
