@@ -106,7 +106,26 @@ __device__ __forceinline__ void glds16_sb(const char* sbase, unsigned voff, unsi
 // asm-ordered) instruction stream. hipcc's sinking passes otherwise move the softmax arithmetic of a slot to its first use.
 #define UV_PIN(x) asm volatile("" : "+v"(x))
 
+// Diagnostic build only (tools/pw4_diag.hip compiles this file with -DUV_PW4_DIAG; the library never does): in-kernel stamps around
+// the main loop and timing-only ablations. Stamp values go to a buffer of their own; no output value is computed from them.
+#ifdef UV_PW4_DIAG
+__device__ unsigned long long* uv_pw4_dbg;
+#ifndef UV_PW4_ABL
+#define UV_PW4_ABL 0
+#endif
+#else
+#define UV_PW4_ABL 0
+#endif
+#define UV_ABL_NO_DMA 1
+#define UV_ABL_NO_FIN 2
+#define UV_ABL_NO_START 4
+#define UV_ABL_NO_LDS 8
+#define UV_ABL_NO_BARRIER 16
+#define UV_ABL_NO_RESCALE 32
+
+#ifndef UV_PW4_PD
 #define UV_PW4_PD 2   // fragment reads issued this many fragments (= 2 MFMAs each) ahead of their first use
+#endif
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn_pw4_kernel(AttnArgs p) {
     constexpr int KROW = 256, K_BYTES = UV_ATT_KV * KROW, V_BYTES = 128 * 128, V_OFF = 2 * K_BYTES;
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         sfor<32>([&](auto nt_) {
             constexpr int n = decltype(nt_)::value;
-            if constexpr (DO_FIN) {
+            if constexpr (DO_FIN && !(UV_PW4_ABL & UV_ABL_NO_FIN)) {
                 // exp2 / row sum / bf16 of two S values of tile i: block X, half T, elements e0, e0+1 in the reference order
                 constexpr int X = (n >> 3) & 1, T = n >> 4, e0 = 2 * (n & 7);
                 const float p0 = __builtin_amdgcn_exp2f(S[CUR][X][T][e0]);
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             if constexpr (DO_QK) {
                 constexpr int X = n & 1, f = n >> 1, kk = f & 7, T = f >> 3;
-                if constexpr ((n & 1) == 0 && f + PD < 16) {
+                if constexpr ((n & 1) == 0 && f + PD < 16 && !(UV_PW4_ABL & UV_ABL_NO_LDS)) {
                     constexpr int g = f + PD;
                     kq[g % 3] = *(lds_frag_q)(kaddr[g & 7] + KRS * K_BYTES + (g >> 3) * 32 * KROW);
                 }
@@ -300,16 +319,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 constexpr int X = n & 1, g = n >> 1, d = g & 3, s2 = (g >> 2) & 1, T = g >> 3;
                 if constexpr (n == 0 || n == 16) {
                     // the reference rescales O between the decision of half T and its P.V
-                    if (flag[0][T]) rescale(std::integral_constant<int, 0>{}, alpha[0][T]);
-                    if (flag[1][T]) rescale(std::integral_constant<int, 1>{}, alpha[1][T]);
+                    if constexpr (!(UV_PW4_ABL & UV_ABL_NO_RESCALE)) {
+                        if (flag[0][T]) rescale(std::integral_constant<int, 0>{}, alpha[0][T]);
+                        if (flag[1][T]) rescale(std::integral_constant<int, 1>{}, alpha[1][T]);
+                    }
                 }
-                if constexpr ((n & 1) == 0 && g + PD < 16) {
+                if constexpr ((n & 1) == 0 && g + PD < 16 && !(UV_PW4_ABL & UV_ABL_NO_LDS)) {
                     constexpr int g2 = g + PD;
                     vq[g2 % 3] = *(lds_frag_q)(vaddr[g2 >> 3][(g2 >> 2) & 1] + VRS * V_BYTES + (g2 & 3) * 4096);
                 }
                 mfma_pv<64 * X + 16 * d>(vq[g % 3], __builtin_bit_cast(bf16x8, pf[X][T][s2]));
             }
-            if constexpr (DO_START) {
+            if constexpr (DO_START && !(UV_PW4_ABL & UV_ABL_NO_START)) {
                 // ---- row maxima of tile i+1: slots 0-3 the two T = 0 chains, 4-7 the two T = 1 chains (their last MFMA is recent)
                 if constexpr (n < 8) {
                     constexpr int T = n >> 2, q = n & 3;            // chain ops 2q, 2q+1 of both blocks
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 // every wave's reads of K stage PAR^1 (phase 1) and V^T stage PAR (issued by slot 26) are complete; its own
                 // pieces of K(i+2) / V^T(i+1) (issued an iteration ago) have landed
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                if constexpr (!(UV_PW4_ABL & UV_ABL_NO_BARRIER)) __builtin_amdgcn_s_barrier();
                 // head of the next iteration's K fragment queue: K(i+2) from K stage PAR
                 if (!TAIL || i + 2 < nt) {
                     sfor<PD>([&](auto ft) {
@@ -378,7 +399,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (n >= 28 && (DO_QK || DO_START)) {
                 // behind the barrier: this wave's pieces of K(i+3) -> K stage PAR^1 (slots 28, 29) and V^T(i+2) -> V^T stage PAR (30, 31)
                 constexpr int pi0 = 2 * (n & 1);
-                if constexpr (n < 30) {
+                if constexpr (UV_PW4_ABL & UV_ABL_NO_DMA) {
+                } else if constexpr (n < 30) {
                     if (!TAIL || i + 3 < nt) {
                         dma_k(i + 3, pi0, std::integral_constant<bool, !TAIL>{});
                         dma_k(i + 3, pi0 + 1, std::integral_constant<bool, !TAIL>{});
@@ -410,10 +432,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //        i   PAR   QK    FIN   PV    START MASK  TAIL
     iter(-1, P1{}, T_{}, F{}, F{}, T_{}, F{}, F{});                   // prologue: QK^T(0), start(0); DMA K(2), V^T(1)
     int i = 0;
+#ifdef UV_PW4_DIAG
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     for (; i + 4 < nt_full; i += 2) {
         iter(i, P0{}, T_{}, T_{}, T_{}, T_{}, F{}, F{});
         iter(i + 1, P1{}, T_{}, T_{}, T_{}, T_{}, F{}, F{});
     }
+#ifdef UV_PW4_DIAG
+    if (lane == 0 && uv_pw4_dbg) {
+        unsigned long long* d = uv_pw4_dbg + ((long)blockIdx.x * 4 + wave_u) * 4;
+        d[0] = __builtin_amdgcn_s_memtime() - st0;
+        d[1] = __builtin_amdgcn_s_memrealtime() - sr0;
+        d[2] = (unsigned long long)i;
+    }
+#endif
     for (; i < nt - 1; ++i) {
         const bool masked = (i + 1 == nt - 1) && nt_full < nt;
         if (i & 1) {
