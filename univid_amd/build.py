@@ -22,7 +22,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-va
 
 # per-file additions. attn_pw4.hip: its slots are hand-placed scalar f32 operations beside MFMAs; SLP-packing them into v_pk_*_f32
 # costs issue cycles there (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
-FILE_FLAGS = {"attn_pw4.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"attn_pw4.hip": ["-fno-slp-vectorize", "-Wno-inline-asm"]}
 
 
 def _hipcc():

@@ -81,6 +81,57 @@ __device__ __forceinline__ float vmax(float a, float b) {
     asm volatile("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+// ---- softmax fillers as ONE asm statement per slot. hipcc pads every asm statement whose outputs the next vector instruction touches
+// with an s_nop and knows nothing of the hazards inside; written out, a slot's filler has no pad and its only hazard (a v_exp_f32
+// result needs one wait state before a non-transcendental VALU reads it) is covered by the instruction order:
+//     exp p0 ; exp p1 ; psum (+)= p0 ; pw = cvt_pk(p0, p1) ; psum += p1   [; l = l * alpha ; l = l + psum]
+// MODE 0: first pair of a (block, half): psum = p0 (the reference starts from 0 + p0, the same value); 2: last pair, folds the
+// row-sum update l = l * alpha + psum (two roundings, as the reference's `l *= alpha; l += psum`).
+template <int MODE>
+__device__ __forceinline__ uint32_t fin_pair(float s0, float s1, float& psum, float& l, float alpha) {
+    uint32_t pw;
+    float p0, p1;
+    if constexpr (MODE == 0)
+        asm volatile("v_exp_f32 %0, %4\n\tv_exp_f32 %1, %5\n\tv_mov_b32 %2, %0\n\tv_cvt_pk_bf16_f32 %3, %0, %1\n\tv_add_f32 %2, %2, %1"
+                     : "=&v"(p0), "=&v"(p1), "=&v"(psum), "=&v"(pw) : "v"(s0), "v"(s1));
+    else if constexpr (MODE == 1)
+        asm volatile("v_exp_f32 %0, %4\n\tv_exp_f32 %1, %5\n\tv_add_f32 %2, %2, %0\n\tv_cvt_pk_bf16_f32 %3, %0, %1\n\tv_add_f32 %2, %2, %1"
+                     : "=&v"(p0), "=&v"(p1), "+v"(psum), "=&v"(pw) : "v"(s0), "v"(s1));
+    else
+        asm volatile("v_exp_f32 %0, %5\n\tv_exp_f32 %1, %6\n\tv_add_f32 %2, %2, %0\n\tv_cvt_pk_bf16_f32 %3, %0, %1\n\tv_add_f32 %2, %2, %1\n\t"
+                     "v_mul_f32 %4, %4, %7\n\tv_add_f32 %4, %4, %2"
+                     : "=&v"(p0), "=&v"(p1), "+v"(psum), "=&v"(pw), "+v"(l) : "v"(s0), "v"(s1), "v"(alpha));
+    return pw;
+}
+// row-maximum chains of both blocks, two ops each per slot: Q = 0 starts them (5 values), 1 / 2 continue (4 values), 3 ends (3 values)
+template <int Q>
+__device__ __forceinline__ void max_step(float& ma, float& mb, const f32x16& a, const f32x16& b) {
+    if constexpr (Q == 0)
+        asm volatile("v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %7, %8, %9\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %1, %1, %10, %11"
+                     : "=&v"(ma), "=&v"(mb)
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]));
+    else if constexpr (Q < 3)
+        asm volatile("v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %8, %9"
+                     : "+v"(ma), "+v"(mb)
+                     : "v"(a[4 * Q + 1]), "v"(a[4 * Q + 2]), "v"(a[4 * Q + 3]), "v"(a[4 * Q + 4]), "v"(b[4 * Q + 1]), "v"(b[4 * Q + 2]),
+                       "v"(b[4 * Q + 3]), "v"(b[4 * Q + 4]));
+    else
+        asm volatile("v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %5, %6\n\tv_max_f32 %0, %0, %4\n\tv_max_f32 %1, %1, %7"
+                     : "+v"(ma), "+v"(mb) : "v"(a[13]), "v"(a[14]), "v"(a[15]), "v"(b[13]), "v"(b[14]), "v"(b[15]));
+}
+// the other half-wave's maximum for two chains: copy, v_permlane32_swap (lanes 32-63 of the first operand <-> lanes 0-31 of the
+// second: afterwards one register holds the low half-wave's value in both halves, the other the high one's), maximum. The swap reads
+// registers a VALU wrote: two wait states (the second v_mov and the s_nop serve the first pair, the s_nop and the first swap the second).
+__device__ __forceinline__ void max_xhalf(float& ma, float& mb) {
+    float ta, tb;
+    asm volatile("v_mov_b32 %2, %0\n\tv_mov_b32 %3, %1\n\ts_nop 0\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+                 "v_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %3"
+                 : "+v"(ma), "+v"(mb), "=&v"(ta), "=&v"(tb));
+}
+// s = s * c + mneg on four accumulator registers (in place); a macro: vector elements cannot bind to references
+#define UV_FMA4(S_, E0, C_, MNEG)                                                                                                   \
+    asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5" \
+                 : "+v"(S_[E0]), "+v"(S_[E0 + 1]), "+v"(S_[E0 + 2]), "+v"(S_[E0 + 3]) : "s"(C_), "v"(MNEG))
 // S^T (VGPRs) = / += Kfrag (VGPRs) . Qfrag (AGPRs a[QB:QB+3])
 template <int QB, bool FIRST> __device__ __forceinline__ void mfma_qk(f32x16& s, const bf16x8& kf) {
     if constexpr (FIRST)
@@ -93,13 +144,102 @@ template <int OB> __device__ __forceinline__ void mfma_pv(const bf16x8& vf, cons
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vf), "v"(pf), "n"(OB), "n"(OB + 15) : UV_ACL_O, UV_ACL_Q);
 }
 
-// One LDS-DMA piece, uniform (SGPR) base + 32-bit lane offset; M0 = LDS byte address of the piece (see attention.hip).
+
+// ---- one asm statement per slot of the steady-state loop: the MFMA first, then its fillers (hipcc puts an s_nop between two adjacent
+// asm statements; a slot written as one statement has none). Same instructions and order as the separate helpers above.
+#define UV_ACL_ALL UV_ACL_O, UV_ACL_Q
+// QK^T MFMA + finish of one pair, SOFTWARE-PIPELINED over the slots: the slot consumes the exponentials (p0c, p1c) the PREVIOUS slot issued
+// and issues the next slot's (p0n, p1n). A v_exp_f32 result takes ~30 cycles to arrive; consumed in the slot that issued it, the lone
+// wave stood still for that long in every slot (measured: 55 cycles per slot for 36 cycles of issue).
+//   MODE 0: first pair of a (block, half): psum = p0;  1: psum += p0;  2: last pair, also l = l * alpha + psum.  LAST: slot 31, no next pair.
+template <int MODE, int QB, bool FIRST, bool LAST>
+__device__ __forceinline__ uint32_t qk_fin(f32x16& sn, const bf16x8& kf, float& p0c, float& p1c, float s0n, float s1n, float& psum, float& l,
+                                           float alpha) {
+    uint32_t pw;
+    float p0n = 0.f, p1n = 0.f;
+#define UV_QKF_BODY(SUM0) "v_exp_f32 %0, %7\n\tv_exp_f32 %1, %8\n\t" SUM0 "\n\tv_cvt_pk_bf16_f32 %3, %5, %6\n\tv_add_f32 %2, %2, %6"
+    if constexpr (LAST) {
+        static_assert(MODE == 2 && !FIRST, "slot 31 ends a (block, half)");
+        asm volatile("v_mfma_f32_32x32x16_bf16 %2, %7, a[%c8:%c9], %2\n\tv_add_f32 %0, %0, %4\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\tv_add_f32 %0, %0, %5\n\t"
+                     "v_mul_f32 %3, %3, %6\n\tv_add_f32 %3, %3, %0"
+                     : "+v"(psum), "=&v"(pw), "+v"(sn), "+v"(l) : "v"(p0c), "v"(p1c), "v"(alpha), "v"(kf), "n"(QB), "n"(QB + 3) : UV_ACL_ALL);
+    } else if constexpr (MODE == 2) {
+        static_assert(!FIRST, "a chain's first MFMA never coincides with the last pair of a (block, half)");
+        asm volatile("v_mfma_f32_32x32x16_bf16 %4, %11, a[%c12:%c13], %4\n\tv_exp_f32 %0, %8\n\tv_exp_f32 %1, %9\n\tv_add_f32 %2, %2, %6\n\t"
+                     "v_cvt_pk_bf16_f32 %3, %6, %7\n\tv_add_f32 %2, %2, %7\n\tv_mul_f32 %5, %5, %10\n\tv_add_f32 %5, %5, %2"
+                     : "=&v"(p0n), "=&v"(p1n), "+v"(psum), "=&v"(pw), "+v"(sn), "+v"(l)
+                     : "v"(p0c), "v"(p1c), "v"(s0n), "v"(s1n), "v"(alpha), "v"(kf), "n"(QB), "n"(QB + 3) : UV_ACL_ALL);
+    } else if constexpr (FIRST && MODE == 0) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %4, %9, a[%c10:%c11], 0\n\t" UV_QKF_BODY("v_mov_b32 %2, %5")
+                     : "=&v"(p0n), "=&v"(p1n), "=&v"(psum), "=&v"(pw), "=&v"(sn)
+                     : "v"(p0c), "v"(p1c), "v"(s0n), "v"(s1n), "v"(kf), "n"(QB), "n"(QB + 3) : UV_ACL_ALL);
+    } else if constexpr (FIRST) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %4, %9, a[%c10:%c11], 0\n\t" UV_QKF_BODY("v_add_f32 %2, %2, %5")
+                     : "=&v"(p0n), "=&v"(p1n), "+v"(psum), "=&v"(pw), "=&v"(sn)
+                     : "v"(p0c), "v"(p1c), "v"(s0n), "v"(s1n), "v"(kf), "n"(QB), "n"(QB + 3) : UV_ACL_ALL);
+    } else if constexpr (MODE == 0) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %4, %9, a[%c10:%c11], %4\n\t" UV_QKF_BODY("v_mov_b32 %2, %5")
+                     : "=&v"(p0n), "=&v"(p1n), "=&v"(psum), "=&v"(pw), "+v"(sn)
+                     : "v"(p0c), "v"(p1c), "v"(s0n), "v"(s1n), "v"(kf), "n"(QB), "n"(QB + 3) : UV_ACL_ALL);
+    } else {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %4, %9, a[%c10:%c11], %4\n\t" UV_QKF_BODY("v_add_f32 %2, %2, %5")
+                     : "=&v"(p0n), "=&v"(p1n), "+v"(psum), "=&v"(pw), "+v"(sn)
+                     : "v"(p0c), "v"(p1c), "v"(s0n), "v"(s1n), "v"(kf), "n"(QB), "n"(QB + 3) : UV_ACL_ALL);
+    }
+#undef UV_QKF_BODY
+    p0c = p0n;
+    p1c = p1n;
+    return pw;
+}
+// the exponentials of the NEXT iteration's first pair, issued with the last P.V MFMA of phase 2 (or alone, in the prologue)
+__device__ __forceinline__ void exp_pair(float& p0c, float& p1c, float s0, float s1) {
+    asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=&v"(p0c), "=&v"(p1c) : "v"(s0), "v"(s1));
+}
+template <int OB>
+__device__ __forceinline__ void pv_exp_pair(const bf16x8& vf, const bf16x8& pf, float& p0c, float& p1c, float s0, float s1) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c6:%c7], %4, %5, a[%c6:%c7]\n\tv_exp_f32 %0, %2\n\tv_exp_f32 %1, %3"
+                 : "=&v"(p0c), "=&v"(p1c) : "v"(s0), "v"(s1), "v"(vf), "v"(pf), "n"(OB), "n"(OB + 15) : UV_ACL_ALL);
+}
+#define UV_PV_TXT(VF, PF, LO, HI) "v_mfma_f32_32x32x16_bf16 a[%c" #LO ":%c" #HI "], %" #VF ", %" #PF ", a[%c" #LO ":%c" #HI "]\n\t"
+template <int OB, int Q>
+__device__ __forceinline__ void pv_max(const bf16x8& vf, const bf16x8& pf, float& ma, float& mb, const f32x16& a, const f32x16& b) {
+    if constexpr (Q == 0)
+        asm volatile(UV_PV_TXT(12, 13, 14, 15)
+                     "v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %7, %8, %9\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %1, %1, %10, %11"
+                     : "=&v"(ma), "=&v"(mb)
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]),
+                       "v"(vf), "v"(pf), "n"(OB), "n"(OB + 15) : UV_ACL_ALL);
+    else if constexpr (Q < 3)
+        asm volatile(UV_PV_TXT(10, 11, 12, 13)
+                     "v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %8, %9"
+                     : "+v"(ma), "+v"(mb)
+                     : "v"(a[4 * Q + 1]), "v"(a[4 * Q + 2]), "v"(a[4 * Q + 3]), "v"(a[4 * Q + 4]), "v"(b[4 * Q + 1]), "v"(b[4 * Q + 2]),
+                       "v"(b[4 * Q + 3]), "v"(b[4 * Q + 4]), "v"(vf), "v"(pf), "n"(OB), "n"(OB + 15) : UV_ACL_ALL);
+    else
+        asm volatile(UV_PV_TXT(8, 9, 10, 11)
+                     "v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %5, %6\n\tv_max_f32 %0, %0, %4\n\tv_max_f32 %1, %1, %7"
+                     : "+v"(ma), "+v"(mb) : "v"(a[13]), "v"(a[14]), "v"(a[15]), "v"(b[13]), "v"(b[14]), "v"(b[15]),
+                       "v"(vf), "v"(pf), "n"(OB), "n"(OB + 15) : UV_ACL_ALL);
+}
+template <int OB>
+__device__ __forceinline__ void pv_xhalf(const bf16x8& vf, const bf16x8& pf, float& ma, float& mb) {
+    float ta, tb;
+    asm volatile(UV_PV_TXT(4, 5, 6, 7)
+                 "v_mov_b32 %2, %0\n\tv_mov_b32 %3, %1\n\ts_nop 0\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+                 "v_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %3"
+                 : "+v"(ma), "+v"(mb), "=&v"(ta), "=&v"(tb) : "v"(vf), "v"(pf), "n"(OB), "n"(OB + 15) : UV_ACL_ALL);
+}
+#define UV_PV_FMA4(OB, VF, PF, S_, E0, C_, MNEG)                                                                                    \
+    asm volatile(UV_PV_TXT(6, 7, 8, 9)                                                                                              \
+                 "v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5"       \
+                 : "+v"(S_[E0]), "+v"(S_[E0 + 1]), "+v"(S_[E0 + 2]), "+v"(S_[E0 + 3])                                                 \
+                 : "s"(C_), "v"(MNEG), "v"(VF), "v"(PF), "n"(OB), "n"((OB) + 15) : UV_ACL_ALL)
+
+// One LDS-DMA piece, uniform (SGPR) base + 32-bit lane offset; M0 = LDS byte address of the piece. M0 is declared clobbered instead of
+// saved and restored (hipcc warns that it is a reserved register; nothing else in this kernel keeps a value in it): three
+// instructions per piece.
 __device__ __forceinline__ void glds16_sb(const char* sbase, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
 // Empty asm with the value as an in/out operand: everything the value depends on is computed BEFORE this point of the (volatile-
@@ -159,19 +299,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float c = p.scale_log2;
 
     // ---- LDS-DMA pieces of this wave (4 of K = 4 LDS rows each, 4 of V^T = 8 rows each per tile; flash_attn_fwd3_kernel's map)
-    unsigned koff, voff;
+    unsigned koff[4], voff[4];       // lane offset of piece pi from the tile's base (piece stride folded in: no scalar address add per piece)
     {
         const int lrow = wave_u * 4 + (lane >> 4);
         const int cc = (lane & 15) ^ (lrow & 15);
-        koff = (unsigned)(perm23(lrow) * (int)p.ldk + cc * 8) * 2u;
         const int drow = wave_u * 8 + (lane >> 3);
         const int cv = (lane & 7) ^ ((drow >> 1) & 7);
-        voff = (unsigned)(drow * (int)p.ldvt + cv * 8) * 2u;
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            koff[pi] = (unsigned)((perm23(lrow) + 16 * pi) * (int)p.ldk + cc * 8) * 2u;
+            voff[pi] = (unsigned)((drow + 32 * pi) * (int)p.ldvt + cv * 8) * 2u;
+        }
     }
     const char* const k0 = (const char*)(p.k + hcol);                 // K tile t: k0 + t * kstep
     const char* const v0 = (const char*)(p.vt + hcol * p.ldvt);       // V^T tile t: v0 + t * 128 bytes
     const long kstep = (long)UV_ATT_KV * p.ldk * 2;
-    const long kpiece = 16 * p.ldk * 2, vpiece = 32 * p.ldvt * 2;
     const unsigned smem_a = (unsigned)(uintptr_t)(lds_void_p*)smem;
     const unsigned lds0 = smem_a + wave_u * 1024;
     const int nt = (p.Lk + UV_ATT_KV - 1) / UV_ATT_KV;
@@ -179,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // piece pi (0..3) of this wave's share of K tile t -> K stage t & 1; FULL: the tile lies inside [0, Lk) for sure
     auto dma_k = [&](int t, int pi, auto full_t) __attribute__((always_inline)) {
         if (decltype(full_t)::value || t < nt_full) {
-            glds16_sb(k0 + t * kstep + pi * kpiece, koff, lds0 + (t & 1) * K_BYTES + pi * 4096);
+            glds16_sb(k0 + t * kstep, koff[pi], lds0 + (t & 1) * K_BYTES + pi * 4096);
         } else {                                                       // the ragged last tile: clamped key rows
             const int lrow = (pi * 4 + wave_u) * 4 + (lane >> 4);
             const int cc = (lane & 15) ^ (lrow & 15);
@@ -189,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     auto dma_v = [&](int t, int pi) __attribute__((always_inline)) {    // V^T tile t -> V^T stage t & 1
-        glds16_sb(v0 + (long)t * (2 * UV_ATT_KV) + pi * vpiece, voff, lds0 + V_OFF + (t & 1) * V_BYTES + pi * 4096);
+        glds16_sb(v0 + (long)t * (2 * UV_ATT_KV), voff[pi], lds0 + V_OFF + (t & 1) * V_BYTES + pi * 4096);
     };
 
     // ---- first tiles on their way before anything else: K(0), V^T(0), K(1)
@@ -231,11 +373,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- state
     f32x16 S[2][2][2];              // [tile parity][block X][key half T]: S^T, then (in place) S*c - m*c
     u32x4 pf[2][2][2];              // [X][T][s2]: P^T fragments (8 bf16) of the tile in phase 2
-    bf16x8 kq[3], vq[3];            // fragment queues
+    bf16x8 kq[3], vq[3];            // fragment queues: ONE ds_read_b128 straight into the register tuple the MFMA reads (assembled from two
+                                    // ds_read_b64, hipcc copies the halves together with v_mov right in front of the asm MFMA, which
+                                    // then reads stale registers: a VALU write needs wait states before an MFMA reads it)
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float mneg_run[2] = {0.f, 0.f};                    // -m_run * c (set with the first tile's decision, which always moves m)
     float alpha[2][2] = {{1.f, 1.f}, {1.f, 1.f}};      // [X][T] of the tile whose P.V comes next
     bool flag[2][2] = {{false, false}, {false, false}};
     float psum = 0.f;
+    float p0c = 0.f, p1c = 0.f;     // exponentials of the pair the next finish slot consumes (issued one slot earlier)
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -250,6 +396,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             acc_write_o<64 * X + e>(v * a);
         });
         asm volatile("s_nop 7" ::: "memory");
+    };
+
+    // K fragment f (key half f >> 3, k-step f & 7) of K stage ks / V^T fragment g (key half, s2, d tile) of V^T stage vs
+    auto ld_k = [&](bf16x8& dst, int f, int ks) __attribute__((always_inline)) {
+        dst = *(lds_frag_q)(kaddr[f & 7] + ks * K_BYTES + (f >> 3) * 32 * KROW);
+    };
+    auto ld_v = [&](bf16x8& dst, int g, int vs) __attribute__((always_inline)) {
+        dst = *(lds_frag_q)(vaddr[g >> 3][(g >> 2) & 1] + vs * V_BYTES + (g & 3) * 4096);
     };
 
     // One iteration i (PAR = i & 1):  phase 1 = [QK^T(i+1)] beside [finish(i)],  phase 2 = [P.V(i)] beside [start(i+1)].
@@ -267,120 +421,105 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // the prologue has no preceding slot 28: fragment queue head from scratch
             sfor<PD>([&](auto ft) {
                 constexpr int f = decltype(ft)::value;
-                kq[f % 3] = *(lds_frag_q)(kaddr[f & 7] + KRS * K_BYTES + (f >> 3) * 32 * KROW);
+                ld_k(kq[f % 3], f, KRS);
             });
         }
         sfor<32>([&](auto nt_) {
             constexpr int n = decltype(nt_)::value;
-            if constexpr (DO_FIN && !(UV_PW4_ABL & UV_ABL_NO_FIN)) {
-                // exp2 / row sum / bf16 of two S values of tile i: block X, half T, elements e0, e0+1 in the reference order
-                constexpr int X = (n >> 3) & 1, T = n >> 4, e0 = 2 * (n & 7);
-                const float p0 = __builtin_amdgcn_exp2f(S[CUR][X][T][e0]);
-                const float p1 = __builtin_amdgcn_exp2f(S[CUR][X][T][e0 + 1]);
-                if constexpr ((n & 7) == 0) psum = p0;
-                else psum += p0;
-                psum += p1;
-                uint32_t pw;                     // volatile: pins exp2 / cvt of this slot (hipcc otherwise sinks them to phase 2)
-                // (s_nop 0: a v_exp_f32 result needs one wait state before a non-transcendental VALU reads it, and hipcc pads nothing
-                // in front of an asm consumer)
-                asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pw) : "v"(p0), "v"(p1));
-                UV_PIN(psum);
-                pf[X][T][e0 >> 3][(e0 & 7) >> 1] = pw;
-                if constexpr ((n & 7) == 7) {
-                    l_run[X] *= alpha[X][T];
-                    l_run[X] += psum;
-                    UV_PIN(l_run[X]);
-                }
+            constexpr bool FIN = DO_FIN && !(UV_PW4_ABL & UV_ABL_NO_FIN);
+            // finish: exp2 / row sum / bf16 of two S values of tile i: block FX, half FT, elements e0, e0+1 in the reference order
+            constexpr int FX = (n >> 3) & 1, FT = n >> 4, e0 = 2 * (n & 7), MODE = (n & 7) == 0 ? 0 : ((n & 7) == 7 ? 2 : 1);
+            // QK^T: block X, fragment f = (half T, k-step kk)
+            constexpr int X = n & 1, f = n >> 1, kk = f & 7, T = f >> 3;
+            if constexpr (DO_QK && (n & 1) == 0 && f + PD < 16 && !(UV_PW4_ABL & UV_ABL_NO_LDS)) ld_k(kq[(f + PD) % 3], f + PD, KRS);
+            if constexpr (DO_QK && FIN) {
+                // elements of the NEXT slot's pair (its exponentials are issued here)
+                constexpr int n1 = n < 31 ? n + 1 : 31, NX = (n1 >> 3) & 1, NT_ = n1 >> 4, ne0 = 2 * (n1 & 7);
+                pf[FX][FT][e0 >> 3][(e0 & 7) >> 1] = qk_fin<MODE, 128 + 32 * X + 4 * kk, kk == 0, n == 31>(
+                    S[NXT][X][T], kq[f % 3], p0c, p1c, S[CUR][NX][NT_][ne0], S[CUR][NX][NT_][ne0 + 1], psum, l_run[FX], alpha[FX][FT]);
             }
-            if constexpr (DO_QK) {
-                constexpr int X = n & 1, f = n >> 1, kk = f & 7, T = f >> 3;
-                if constexpr ((n & 1) == 0 && f + PD < 16 && !(UV_PW4_ABL & UV_ABL_NO_LDS)) {
-                    constexpr int g = f + PD;
-                    kq[g % 3] = *(lds_frag_q)(kaddr[g & 7] + KRS * K_BYTES + (g >> 3) * 32 * KROW);
-                }
+            else if constexpr (DO_QK)
                 mfma_qk<128 + 32 * X + 4 * kk, kk == 0>(S[NXT][X][T], kq[f % 3]);
-            }
+            else if constexpr (FIN)
+                pf[FX][FT][e0 >> 3][(e0 & 7) >> 1] = fin_pair<MODE>(S[CUR][FX][FT][e0], S[CUR][FX][FT][e0 + 1], psum, l_run[FX], alpha[FX][FT]);
             __builtin_amdgcn_sched_barrier(0);
         });
 
         // ================= phase 2 =================
-        float mx[4], mt[4], mneg[4];           // combos cb = X + 2 T
+        float mx[4], mneg_t[4];                // combos cb = X + 2 T
         float alpha_n[2][2];
         bool flag_n[2][2];
         if constexpr (DO_PV) {
             sfor<PD>([&](auto gt) {
                 constexpr int g = decltype(gt)::value;
-                vq[g % 3] = *(lds_frag_q)(vaddr[g >> 3][(g >> 2) & 1] + VRS * V_BYTES + (g & 3) * 4096);
+                ld_v(vq[g % 3], g, VRS);
             });
         }
         sfor<32>([&](auto nt_) {
             constexpr int n = decltype(nt_)::value;
+            constexpr bool START = DO_START && !(UV_PW4_ABL & UV_ABL_NO_START);
+            constexpr int X = n & 1, g = n >> 1, d = g & 3, s2 = (g >> 2) & 1, T = g >> 3, OB = 64 * X + 16 * d;     // P.V of this slot
             if constexpr (DO_PV) {
-                constexpr int X = n & 1, g = n >> 1, d = g & 3, s2 = (g >> 2) & 1, T = g >> 3;
-                if constexpr (n == 0 || n == 16) {
+                if constexpr ((n == 0 || n == 16) && !(UV_PW4_ABL & UV_ABL_NO_RESCALE)) {
                     // the reference rescales O between the decision of half T and its P.V
-                    if constexpr (!(UV_PW4_ABL & UV_ABL_NO_RESCALE)) {
-                        if (flag[0][T]) rescale(std::integral_constant<int, 0>{}, alpha[0][T]);
-                        if (flag[1][T]) rescale(std::integral_constant<int, 1>{}, alpha[1][T]);
-                    }
+                    if (flag[0][T]) rescale(std::integral_constant<int, 0>{}, alpha[0][T]);
+                    if (flag[1][T]) rescale(std::integral_constant<int, 1>{}, alpha[1][T]);
                 }
-                if constexpr ((n & 1) == 0 && g + PD < 16 && !(UV_PW4_ABL & UV_ABL_NO_LDS)) {
-                    constexpr int g2 = g + PD;
-                    vq[g2 % 3] = *(lds_frag_q)(vaddr[g2 >> 3][(g2 >> 2) & 1] + VRS * V_BYTES + (g2 & 3) * 4096);
-                }
-                mfma_pv<64 * X + 16 * d>(vq[g % 3], __builtin_bit_cast(bf16x8, pf[X][T][s2]));
+                if constexpr ((n & 1) == 0 && g + PD < 16 && !(UV_PW4_ABL & UV_ABL_NO_LDS)) ld_v(vq[(g + PD) % 3], g + PD, VRS);
             }
-            if constexpr (DO_START && !(UV_PW4_ABL & UV_ABL_NO_START)) {
-                // ---- row maxima of tile i+1: slots 0-3 the two T = 0 chains, 4-7 the two T = 1 chains (their last MFMA is recent)
-                if constexpr (n < 8) {
-                    constexpr int T = n >> 2, q = n & 3;            // chain ops 2q, 2q+1 of both blocks
+            const bf16x8 pfr = __builtin_bit_cast(bf16x8, pf[X][T][s2]), vfr = vq[g % 3];
+            // start of tile i+1 beside it. Row maxima: slots 0-3 the two T = 0 chains, 4-7 the two T = 1 chains (their last MFMA is
+            // recent); 8, 9: the other half-wave's maximum (combos cb = X + 2 T); 12-27: S*c - m*c in place, (A,0) (B,0) (A,1) (B,1)
+            if constexpr (START && n < 8) {
+                constexpr int MT = n >> 2, q = n & 3;            // chain ops 2q, 2q+1 of both blocks
+                if (q == 0 && MASK && (i + 1) * UV_ATT_KV + UV_ATT_KV > p.Lk) {      // tile i+1 is the ragged last tile (wave-uniform, rare)
+                    const int kv0 = (i + 1) * UV_ATT_KV;
                     sfor<2>([&](auto xt) {
-                        constexpr int X = decltype(xt)::value, cb = X + 2 * T;
-                        f32x16& s = S[NXT][X][T];
-                        if constexpr (MASK && q == 0) {
-                            const int kv0 = (i + 1) * UV_ATT_KV;
+                        f32x16& sm = S[NXT][decltype(xt)::value][MT];
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const int ki = 32 * T + (e & 3) + 8 * (e >> 2) + 4 * h;
-                                if (kv0 + perm23(ki) >= p.Lk) s[e] = -INFINITY;
-                            }
+                        for (int e = 0; e < 16; ++e) {
+                            const int ki = 32 * MT + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            if (kv0 + perm23(ki) >= p.Lk) sm[e] = -INFINITY;
                         }
-                        if constexpr (q == 0) mx[cb] = vmax5(s[0], s[1], s[2], s[3], s[4]);
-                        else if constexpr (q < 3) mx[cb] = vmax5(mx[cb], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3], s[4 * q + 4]);
-                        else mx[cb] = vmax4(mx[cb], s[13], s[14], s[15]);
                     });
                 }
-                // ---- the other half-wave's maximum
-                if constexpr (n == 8 || n == 9) {
-                    sfor<2>([&](auto xt) {
-                        constexpr int cb = decltype(xt)::value + 2 * (n - 8);
-                        const unsigned u = __builtin_bit_cast(unsigned, mx[cb]);
-                        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                        mt[cb] = vmax(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
-                    });
+                if constexpr (DO_PV) pv_max<OB, q>(vfr, pfr, mx[2 * MT], mx[2 * MT + 1], S[NXT][0][MT], S[NXT][1][MT]);
+                else max_step<q>(mx[2 * MT], mx[2 * MT + 1], S[NXT][0][MT], S[NXT][1][MT]);
+            } else if constexpr (START && (n == 8 || n == 9)) {
+                if constexpr (DO_PV) pv_xhalf<OB>(vfr, pfr, mx[2 * (n - 8)], mx[2 * (n - 8) + 1]);
+                else max_xhalf(mx[2 * (n - 8)], mx[2 * (n - 8) + 1]);
+            } else if constexpr (START && n >= 14 && n < 28) {
+                constexpr int cb = (n - 12) >> 2, FX = cb & 1, FT = cb >> 1, e0 = 4 * ((n - 12) & 3);
+                f32x16& sm = S[NXT][FX][FT];
+                if constexpr (DO_PV) UV_PV_FMA4(OB, vfr, pfr, sm, e0, c, mneg_t[cb]);
+                else UV_FMA4(sm, e0, c, mneg_t[cb]);
+            } else if constexpr (START && n == 31) {
+                // first pair of the NEXT iteration's finish phase: S[NXT] (A, half 0) was scaled in slots 12-15
+                if constexpr (DO_PV) pv_exp_pair<OB>(vfr, pfr, p0c, p1c, S[NXT][0][0][0], S[NXT][0][0][1]);
+                else exp_pair(p0c, p1c, S[NXT][0][0][0], S[NXT][0][0][1]);
+            } else if constexpr (DO_PV) {
+                mfma_pv<OB>(vfr, pfr);
+            }
+            if constexpr (START && n >= 10 && n < 14) {
+                // deferred-maximum decisions (A,0) (B,0) (A,1) (B,1). Common case: nothing moves (alpha = 1, m and -m*c stay); the
+                // update runs behind a wave-uniform branch. Slots 12, 13 also carry the first two S*c - m*c groups of (A,0).
+                constexpr int cb = n - 10, DX = cb & 1, DT = cb >> 1;
+                const float grow = (mx[cb] - m_run[DX]) * c;
+                const bool cond = __any(grow > UV_ATT_DEFER);
+                alpha_n[DX][DT] = 1.0f;
+                flag_n[DX][DT] = cond;
+                if (cond) {
+                    const float m_new = vmax(m_run[DX], mx[cb]);
+                    alpha_n[DX][DT] = __builtin_amdgcn_exp2f((m_run[DX] - m_new) * c);
+                    m_run[DX] = m_new;
+                    mneg_run[DX] = -m_new * c;
                 }
-                // ---- deferred-maximum decisions, branch-free: (A,0) (B,0) (A,1) (B,1) in slots 10 .. 13
-                if constexpr (n >= 10 && n < 14) {
-                    constexpr int cb = n - 10, X = cb & 1, T = cb >> 1;
-                    const float grow = (mt[cb] - m_run[X]) * c;
-                    const bool cond = __any(grow > UV_ATT_DEFER);
-                    const float m_new = vmax(m_run[X], mt[cb]);
-                    const float a = __builtin_amdgcn_exp2f((m_run[X] - m_new) * c);
-                    alpha_n[X][T] = cond ? a : 1.0f;
-                    m_run[X] = cond ? m_new : m_run[X];
-                    flag_n[X][T] = cond;
-                    mneg[cb] = -m_run[X] * c;
-                    UV_PIN(alpha_n[X][T]);
-                    UV_PIN(m_run[X]);
-                    UV_PIN(mneg[cb]);
-                }
-                // ---- S*c - m*c in place: (A,0) slots 12-15, (B,0) 16-19, (A,1) 20-23, (B,1) 24-27
-                if constexpr (n >= 12 && n < 28) {
-                    constexpr int cb = (n - 12) >> 2, X = cb & 1, T = cb >> 1, e0 = 4 * ((n - 12) & 3);
-                    f32x16& s = S[NXT][X][T];
-#pragma unroll
-                    for (int e = e0; e < e0 + 4; ++e) s[e] = __builtin_fmaf(s[e], c, mneg[cb]);
-                    UV_PIN(s);
+                mneg_t[cb] = mneg_run[DX];
+                UV_PIN(mneg_t[cb]);
+                if constexpr (n >= 12) {
+                    constexpr int e0 = 4 * (n - 12);
+                    f32x16& sm = S[NXT][0][0];
+                    UV_FMA4(sm, e0, c, mneg_t[0]);
                 }
             }
             if constexpr (n == 28 && (DO_QK || DO_START)) {
@@ -392,7 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (!TAIL || i + 2 < nt) {
                     sfor<PD>([&](auto ft) {
                         constexpr int f = decltype(ft)::value;
-                        kq[f % 3] = *(lds_frag_q)(kaddr[f & 7] + PAR * K_BYTES + (f >> 3) * 32 * KROW);
+                        ld_k(kq[f % 3], f, PAR);
                     });
                 }
             }
@@ -431,14 +570,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using P1 = std::integral_constant<int, 1>;
     //        i   PAR   QK    FIN   PV    START MASK  TAIL
     iter(-1, P1{}, T_{}, F{}, F{}, T_{}, F{}, F{});                   // prologue: QK^T(0), start(0); DMA K(2), V^T(1)
+    // steady state: ONE instantiation per tile parity serves every iteration (the DMA / prefetch / mask decisions of the last
+    // iterations are wave-uniform run-time branches; separate tail instantiations made hipcc spill into AGPRs around them)
     int i = 0;
 #ifdef UV_PW4_DIAG
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    for (; i + 4 < nt_full; i += 2) {
-        iter(i, P0{}, T_{}, T_{}, T_{}, T_{}, F{}, F{});
-        iter(i + 1, P1{}, T_{}, T_{}, T_{}, T_{}, F{}, F{});
+    for (;;) {
+        if (i >= nt - 1) break;
+        iter(i, P0{}, T_{}, T_{}, T_{}, T_{}, T_{}, T_{});
+        ++i;
+        if (i >= nt - 1) break;
+        iter(i, P1{}, T_{}, T_{}, T_{}, T_{}, T_{}, T_{});
+        ++i;
     }
 #ifdef UV_PW4_DIAG
     if (lane == 0 && uv_pw4_dbg) {
@@ -448,16 +593,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         d[2] = (unsigned long long)i;
     }
 #endif
-    for (; i < nt - 1; ++i) {
-        const bool masked = (i + 1 == nt - 1) && nt_full < nt;
-        if (i & 1) {
-            if (masked) iter(i, P1{}, T_{}, T_{}, T_{}, T_{}, T_{}, T_{});
-            else iter(i, P1{}, T_{}, T_{}, T_{}, T_{}, F{}, T_{});
-        } else {
-            if (masked) iter(i, P0{}, T_{}, T_{}, T_{}, T_{}, T_{}, T_{});
-            else iter(i, P0{}, T_{}, T_{}, T_{}, T_{}, F{}, T_{});
-        }
-    }
     if (i & 1) iter(i, P1{}, F{}, T_{}, T_{}, F{}, F{}, T_{});        // i = nt - 1: finish + P.V of the last tile
     else iter(i, P0{}, F{}, T_{}, T_{}, F{}, F{}, T_{});
 
