@@ -326,6 +326,34 @@ def test_flash_attention_long_key_kernel(Lk):
     assert (out[:Lq].float() - 1).abs().max() <= 2 ** -7
 
 
+@pytest.mark.parametrize("Lq,Lk,B,scale,spike", [(2048, 2048, 1, 1.0, False), (2100, 2100, 1, 1.0, False), (700, 4000, 2, 1.0, False),
+                                                 (3000, 2992, 2, 2.0, True), (11440, 11440, 2, 1.0, False)])
+def test_flash_attention_pw4_kernel_is_bit_identical_to_fwd12(Lq, Lk, B, scale, spike, monkeypatch):
+    """The two long-key self-attention kernels (the default 12-wave workgroups and the opt-in 4-wave x 64-query kernel with asm-owned
+    accumulator registers, attn_pw4.hip) perform the same per-query arithmetic in the same order: their outputs must agree BIT FOR BIT -
+    full tiles, ragged last tile and ragged last workgroup, stacked samples, spiked keys that move the deferred softmax maximum late
+    in the sequence, and the bench shape. Any hazard or staging slip in the hand-placed kernel shows up here (and did, four times)."""
+    H, D = 24 if Lq > 4096 else 4, 128
+    C = H * D
+    g = torch.Generator(device=DEV).manual_seed(Lq + Lk)
+    q = (torch.randn(B * Lq, C, generator=g, device=DEV) * scale).to(BF16)
+    k = (torch.randn(B * Lk, C, generator=g, device=DEV) * scale).to(BF16)
+    if spike:
+        k[Lk // 2 + 37] *= 6.0
+        k[Lk - 5] *= 9.0
+    vt = torch.randn(C, (B - 1) * Lk + (Lk + 63) // 64 * 64, generator=g, device=DEV).to(BF16)
+    outs = {}
+    for kind in ("fwd12", "pw4"):
+        monkeypatch.setenv("UV_ATTN_LONG", kind)
+        assert (kind == "pw4") == ("pw4" in L().attn_kernel_name(Lq, Lk, D, B, H=H))
+        o = torch.full((B * Lq + 8, C), 7.0, dtype=BF16, device=DEV)
+        L().flash_attn(q, k, vt, o, Lq, Lk, H, D, D ** -0.5, batch=B)
+        assert (o[B * Lq:] == 7.0).all(), f"{kind} wrote past Lq"
+        outs[kind] = o
+    assert torch.isfinite(outs["pw4"].float()).all()
+    assert torch.equal(outs["fwd12"].view(torch.int16), outs["pw4"].view(torch.int16))
+
+
 @pytest.mark.parametrize("spike", [4.0, 0.45, 0.2])
 def test_flash_attention_rescale_branch_and_rowsum(spike):
     """A key that dominates late: spike 4 moves the softmax reference maximum (the rescale branch of the online softmax),

@@ -435,3 +435,21 @@ def test_vae_pass_length_falls_back_when_memory_runs_out():
 
     with pytest.raises(torch.cuda.OutOfMemoryError):
         m._with_pass_length(always)
+
+
+def test_pw4_attention_isa_audit():
+    """The hand-placed self-attention kernel (attn_pw4.hip) owns accumulator registers behind hipcc's back and places its own wait
+    states: the compiled ISA must show no compiler access to a[0:191] outside the asm statements and no vector-ALU write directly in
+    front of an MFMA that reads it (tools/diag/pw4_audit.py; both slips produced wrong tiles during development)."""
+    import importlib.util, os, tempfile
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "diag", "pw4_audit.py")
+    spec = importlib.util.spec_from_file_location("pw4_audit", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "attn_pw4.s")
+        mod.compile_to_asm(out)
+        findings = mod.audit(out)
+        text = open(out).read()
+    assert not findings, findings[:5]
+    assert "scratch_" not in text.split("flash_attn_pw4_kernel")[1].split(".amdhsa_")[0], "the pw4 kernel must not touch scratch memory"

@@ -56,8 +56,8 @@ int main(int argc, char** argv) {
     }
     std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
     const double fl = 4.0 * B * L * (double)L * C;
-    printf("ABL=%d PD=%d L=%d B=%d: %.3f ms/launch  %.1f TFLOP/s | main loop: median %.0f cycles per tile iteration (min %.0f, p90 %.0f) = %.1f cycles per MFMA; clock in the loop %.2f GHz (median)\n",
-           UV_PW4_ABL, UV_PW4_PD, L, B, ms / reps, fl / (ms / reps) / 1e9, cyc[cyc.size() / 2], cyc[0], cyc[cyc.size() * 9 / 10], cyc[cyc.size() / 2] / 64.0,
+    printf("ABL=%d L=%d B=%d: %.3f ms/launch  %.1f TFLOP/s | main loop: median %.0f cycles per tile iteration (min %.0f, p90 %.0f) = %.1f cycles per MFMA; clock in the loop %.2f GHz (median)\n",
+           UV_PW4_ABL, L, B, ms / reps, fl / (ms / reps) / 1e9, cyc[cyc.size() / 2], cyc[0], cyc[cyc.size() * 9 / 10], cyc[cyc.size() / 2] / 64.0,
            clk[clk.size() / 2]);
     return 0;
 }
