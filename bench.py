@@ -34,11 +34,47 @@ GUIDE, SHIFT, SAMPLING_STEPS = 5.0, 5.0, 50
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def dit_forward_flops(L, cfg):
-    """SURVEY.md 8(d) 'Algorithmic work per unit'."""
+def dit_forward_flops(L, cfg, executed=False):
+    """SURVEY.md 8(d) 'Algorithmic work per unit'. executed=True: what a step of the sampling loop actually runs - the context's
+    text_embedding and the blocks' cross-attention K / V projections (4 Lc d^2 per block) are step-constant and computed once per
+    context (WanModel.context_cached), so they are NOT part of a timed step."""
     d, f, Lc, td, n = cfg["dim"], cfg["ffn_dim"], cfg["text_len"], cfg["text_dim"], cfg["num_layers"]
-    per_block = L * (12 * d * d + 4 * d * f) + 4 * Lc * d * d + 4 * L * L * d + 4 * L * Lc * d
-    return n * per_block + 2 * L * 192 * d * 2 + 2 * Lc * (td * d + d * d)
+    ctx_block = 0 if executed else 4 * Lc * d * d
+    ctx_embed = 0 if executed else 2 * Lc * (td * d + d * d)
+    per_block = L * (12 * d * d + 4 * d * f) + ctx_block + 4 * L * L * d + 4 * L * Lc * d
+    return n * per_block + 2 * L * 192 * d * 2 + ctx_embed
+
+
+def hipblaslt_ref(device):
+    """The vendor library on the ffn.0 shape (22880 x 14336 x 3072, the one DiT GEMM shape where it is ahead), next to
+    uv_gemm_bf16_nt in the SAME run and OUTSIDE the timed region: interleaved rounds, random operands, plain bf16 epilogue.
+    Calibration only - the product path never calls a vendor GEMM."""
+    from univid_amd import _lib
+    from univid_amd._lib import EPI_BF16
+    M, N, K = 22880, 14336, 3072
+    g = torch.Generator(device=device).manual_seed(0)
+    A = (torch.rand(M, K, device=device, generator=g) * 2 - 1).to(torch.bfloat16)
+    W = ((torch.rand(N, K, device=device, generator=g) * 2 - 1) * 0.05).to(torch.bfloat16)
+    out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+    res = {"hipblaslt": [], "uv_gemm_bf16_nt": []}
+    fns = {"hipblaslt": lambda: torch.nn.functional.linear(A, W), "uv_gemm_bf16_nt": lambda: _lib.gemm_bf16(A, W, None, out, EPI_BF16)}
+    for _ in range(3):
+        for name, fn in fns.items():
+            for _ in range(2):
+                fn()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(5):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            res[name].append(s.elapsed_time(e) / 5)
+    fl = 2.0 * M * N * K
+    med = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
+    return {"shape": f"{M}x{N}x{K} bf16 (ffn.0)", "hipblaslt_tflops": round(fl / med["hipblaslt"] / 1e9, 1),
+            "uv_gemm_bf16_nt_tflops": round(fl / med["uv_gemm_bf16_nt"] / 1e9, 1),
+            "ratio": round(med["hipblaslt"] / med["uv_gemm_bf16_nt"], 3),
+            "note": "same run, outside the timed region, interleaved; uv time includes its leftover-row launch"}
 
 
 def self_attn_flops(L, d):
@@ -350,7 +386,8 @@ def main():
                         "traffic_source": None if traffic is None else "committed PMC passes (profiles/pmc_traffic.json <- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not this run",
                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(self_ev),
                         "flops_per_launch": launch_flops}
-        step_flops = 2 * dit_forward_flops(L_TOKENS, cfg)
+        step_flops = 2 * dit_forward_flops(L_TOKENS, cfg, executed=True)      # what the timed step executes (context work is cached)
+        step_flops_model = 2 * dit_forward_flops(L_TOKENS, cfg)               # SURVEY 8(d)'s per-step figure (context work included)
         out = {
             "metric": "denoise_steps_per_sec", "value": round((1 if shared else world) * args.steps / dt_max, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 2),
@@ -361,6 +398,8 @@ def main():
                                    "one sample per GPU" % cfg["num_layers"],
                        "samples_per_gpu": 1, "guide_scale": GUIDE, "shift": SHIFT, "parallelism": (f"ulysses sequence parallel x{world}, 4 all-to-alls per block" if use_sp else "cfg pair x2, one all-gather of the prediction per step" if cfgp is not None else f"replicas x{world}, all-gather of final latents")},
             "step_tflop": round(step_flops / 1e12, 1),
+            "step_tflop_note": f"executed per timed step; SURVEY 8(d)'s {round(step_flops_model / 1e12, 1)} TFLOP also counts text_embedding and the "
+                               "cross-attention K/V projections of the (step-constant) context, which run once per context, outside the timed steps",
             "model_tflops_per_gpu": round(step_flops * args.steps / dt_max / 1e12, 1),
             "mfma_frac_whole_step": round(step_flops * args.steps / dt_max / 1e12 / PEAK_BF16_TFLOPS, 4),
             "finite": ok,
@@ -377,6 +416,11 @@ def main():
             x6 = vae_metrics(device, "bf16x6")
             out["vae_decode_bf16x6"], out["vae_encode_bf16x6"] = x6["decode"], x6["encode"]
             out["vae_decode_bf16x3"] = vae_metrics(device, "bf16x3", encode=False)["decode"]
+        if world == 1 and not args.no_vae and not args.layers and args.shape == "A":
+            try:
+                out["hipblaslt_ref"] = hipblaslt_ref(device)
+            except Exception as ex:      # calibration only: never fails the bench
+                out["hipblaslt_ref"] = {"error": repr(ex)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dict(TI2V_5B_CFG))
             if not args.no_vae:

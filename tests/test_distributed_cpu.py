@@ -57,6 +57,29 @@ def test_two_rank_sharding_and_gather(n_samples):
     assert res[0][2] == 0 and res[0][3] == res[1][2] and res[1][3] == n_samples
 
 
+@pytest.mark.parametrize("n_samples", [8, 11, 5])
+def test_eight_rank_sharding_uneven_shards_and_gather(n_samples):
+    """The driver's 8-GPU launch shape on CPU (world 8, gloo): 8 samples (one per rank, the bench's layout), 11 (uneven: three ranks
+    own two samples) and 5 (three ranks own NOTHING and still take part in the one all-gather). Every rank must end with all
+    latents in global sample order, and the shard ranges must tile [0, n) without gap or overlap."""
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_samples, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r for r, *_ in res] == list(range(world)) and all(ok for _, ok, _, _ in res)
+    assert res[0][2] == 0 and res[-1][3] == n_samples
+    assert all(res[r][3] == res[r + 1][2] for r in range(world - 1)), "shard ranges must be contiguous"
+    sizes = [hi - lo for _, _, lo, hi in res]
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) == n_samples
+
+
 def test_seed_depends_on_global_index_only():
     assert parallel.sample_seed(42, 5) == 47
     assert [parallel.sample_seed(42, i) for i in range(*parallel.shard_range(8, 3, 4))] == [48, 49]

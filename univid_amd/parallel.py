@@ -41,10 +41,19 @@ def gather_latents(local: Sequence[torch.Tensor], n_samples: int) -> List[torch.
     if ws == 1:
         return list(local)
     per = (n_samples + ws - 1) // ws
-    if not len(local):
-        raise ValueError("every rank must own at least one sample (n_samples >= world_size)")
-    ref = local[0]
-    buf = torch.zeros(per, *ref.shape, dtype=ref.dtype, device=ref.device)
+    if n_samples < ws:
+        # fewer samples than ranks: the trailing ranks own nothing and learn the latent's shape / dtype from rank 0 (which always owns
+        # sample 0), then take part in the one all-gather with an all-zero buffer
+        meta = [(tuple(local[0].shape), local[0].dtype) if len(local) else None]
+        dist.broadcast_object_list(meta, src=0)
+        shape, dtype = meta[0]
+        if len(local):
+            device = local[0].device
+        else:
+            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    else:
+        shape, dtype, device = tuple(local[0].shape), local[0].dtype, local[0].device
+    buf = torch.zeros(per, *shape, dtype=dtype, device=device)
     for i, t in enumerate(local):
         buf[i].copy_(t)
     out = [torch.empty_like(buf) for _ in range(ws)]
