@@ -18,22 +18,10 @@
 // caller as an input RING [2 + T, H, W, C]: frames 0..1 hold the cached frames (zeros before the first
 // chunk = the causal zero padding), the producer writes frames 2.., and `t_off` selects the first ring frame
 // a kernel tap reads.
-#include "common.h"
+#include "conv_args.h"
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void lds_void_c;
-
-struct ConvArgs {
-    const float* in;     // [Tin, Hin, Win, ld_in] channels-last
-    const float* w;      // [Cout, taps * Cin]
-    const float* bias;   // [Cout] or nullptr
-    const float* resid;  // [M, ldr] or nullptr
-    float* out;
-    const float* zeros;
-    long ld_in, ldo, ldr;
-    int Tout, Hout, Wout, Tin, Hin, Win;
-    int Cin, Cout, kt, kh, kw, st, sh, sw, t_off, ph, pw, up, interleave;
-    int M, tiles_m, tiles_n;
-};
 
 // PREC 0: exact-f32 MFMA (v_mfma_f32_16x16x4_f32), weights f32 [Cout][K].
 // PREC 1: "bf16x3": every f32 operand x is split as hi + lo (two bf16), and x*w ~ xh*wh + xh*wl + xl*wh on the bf16 MFMA
@@ -384,6 +372,12 @@ static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, c
     a.t_off = t_off; a.ph = ph; a.pw = pw; a.up = up; a.interleave = interleave;
     a.M = Tout * Hout * Wout;
     hipStream_t s = (hipStream_t)stream;
+    // the large 3x3(x3) stride-1 convolutions (ResidualBlocks): LDS-halo kernel (conv3d_halo.hip), exact f32 and bf16x6
+    if (uv_conv3d_halo_eligible(a, prec)) {
+        uv_launch_conv3d_halo(a, prec, s);
+        UV_CHECK_LAUNCH("uv_conv3d (halo)");
+        return 0;
+    }
     // tile choice: 256x256 (16 waves, 4 per SIMD) when Cout >= 256 and the grid still fills the chip: halves the A gather
     // per output; 256x128 (8 waves) next; the 4-wave 128x128 tile for the low-resolution stages
     const long t256 = (long)((a.M + 255) / 256) * ((Cout + 255) / 256);

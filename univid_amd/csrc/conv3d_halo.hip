@@ -1,0 +1,293 @@
+// Causal 3x3(x3) stride-1 convolution of the Wan2.2 VAE as an LDS-HALO'd implicit GEMM (the large ResidualBlock convolutions:
+// ~90 % of the decoder's FLOPs), channels-last f32 activations.
+//
+// Replaces (reference, fp32 nn.Conv3d through cuDNN): CausalConv3d.forward  models/wan/utils/modules/vae2_2.py:17-42 as used by
+// ResidualBlock (vae2_2.py:193-235); same arithmetic contract as conv3d_f32_kernel (conv3d_f32.hip), which keeps every other
+// geometry (1x1x1, strided, 2x-upsampling, time_conv, Cout not a multiple of 16 x 8).
+//
+// conv3d_f32_kernel gathers a 128-pixel x 32-channel A tile from L2 for EVERY tap (27 gathers of the same pixels per channel block).
+// Here a workgroup owns an 8 x 32 pixel patch of one frame and stages, once per (input frame dt, 32-channel block), the patch with
+// its one-pixel halo - 10 x 34 pixels - in LDS; the nine spatial taps then read their A fragments from that image at shifted
+// addresses (halo pixel = (y + dh) * 34 + x + dw): 9x less L2 -> LDS traffic and LDS-write work for the activations (x 340 / 256
+// for the halo), half the weight traffic per output (256 instead of 128 pixels per weight tile).
+//   * 8 waves: 4 (pixels) x 2 (output channels), a wave owns 64 pixels x 64 channels (the MFMA tile of conv3d_f32_kernel).
+//   * the halo goes global -> registers -> LDS (six 16-byte loads per lane, issued a whole tap group ahead of their use) because the
+//     f32-grade bf16 arithmetic (PREC 3, "bf16x6") SPLITS on the way: every f32 activation is written as three exact bf16 planes
+//     ONCE per halo element instead of once per (element, tap, wave column) in the MFMA loop - 13x less splitting work, which was
+//     the limiter of that mode. PREC 0 (exact-f32 MFMA) writes the f32 image unchanged.
+//   * weights stream as before: one k-tile (tap, 32 channels) per step, LDS-DMA double buffer, one barrier per k-tile.
+#include "conv_args.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(3))) void lds_void_h;
+
+template <int PREC>
+__global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
+    static_assert(PREC == 0 || PREC == 3, "exact-f32 MFMA or f32-grade bf16x6");
+    constexpr int TH = 8, TW = 32, HW_ = TW + 2, NHP = (TH + 2) * HW_;        // 340 halo pixels
+    constexpr int BN = 128, NW = 8, TM = 4, TN = 4;
+    constexpr int HALO_ROW = PREC == 3 ? 64 : 128;                              // bytes per halo pixel (per plane for PREC 3)
+    constexpr int HALO_PLANE = 344 * HALO_ROW;                                  // 340 pixels padded to whole 8-pixel groups
+    constexpr int HALO_BYTES = (PREC == 3 ? 3 : 1) * HALO_PLANE;
+    constexpr int W_BYTES = PREC == 3 ? BN * 192 : BN * 128;
+    constexpr int W_PIECES = W_BYTES / 1024, W_INSTR = W_PIECES / NW;            // 16 / 24 pieces -> 2 / 3 per wave
+    constexpr int NLD = 6;                                                      // 340 x 8 sixteen-byte chunks over 512 lanes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    char* const wbuf = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_w = (p.Wout + TW - 1) / TW, tiles_h = (p.Hout + TH - 1) / TH;
+    const int tile_n = blockIdx.x % p.tiles_n;
+    int mt = blockIdx.x / p.tiles_n;
+    const int tx0 = (mt % tiles_w) * TW;
+    mt /= tiles_w;
+    const int ty0 = (mt % tiles_h) * TH;
+    const int tf = mt / tiles_h;                                                 // output frame
+    const int n0 = tile_n * BN;
+    const int K = p.kt * 9 * p.Cin;
+    const long frame = (long)p.Hin * p.Win * p.ld_in;
+
+    // ---- halo staging map of this lane: slot s = it * 512 + tid -> halo pixel s / 8, 16-byte chunk (4 channels) s % 8
+    long h_off[NLD];             // element offset of the chunk inside a frame (channel block 0)
+    unsigned h_ok = 0;           // bit it: inside the frame
+    unsigned h_lds[NLD];         // LDS byte offset the chunk (its first plane) is written to
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int s = it * 512 + tid, hp = s >> 3, ch = s & 7;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        const bool ok = hp < NHP && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+        h_ok |= (unsigned)ok << it;
+        h_off[it] = ok ? ((long)y * p.Win + x) * p.ld_in + ch * 4 : 0;
+        if constexpr (PREC == 3) h_lds[it] = hp * 64 + ((((ch >> 1) ^ ((0x1320 >> (4 * ((hp >> 2) & 3))) & 3)) << 4) | ((ch & 1) << 3));
+        else h_lds[it] = hp * 128 + ((ch ^ ((hp >> 1) & 7)) << 4);
+        if (hp >= 344) h_lds[it] = 0xffffffffu;                                // beyond the padded image: never written
+    }
+    f32x4 hreg[NLD];
+    // group g = (dt, channel block cb): dt = g / ncb, cb = g % ncb
+    const int ncb = p.Cin >> 5, ngroups = p.kt * ncb;
+    auto load_halo = [&](int g) __attribute__((always_inline)) {
+        const int dt = g / ncb, cb = g - dt * ncb;
+        const int fi = tf * p.st + p.t_off + dt;
+        const bool fok = (unsigned)fi < (unsigned)p.Tin;
+        const float* base = p.in + (long)(fok ? fi : 0) * frame + cb * 32;
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const bool ok = fok && ((h_ok >> it) & 1u);
+            hreg[it] = *(const f32x4*)(ok ? base + h_off[it] : p.zeros);
+        }
+    };
+    auto write_halo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            if (h_lds[it] == 0xffffffffu) continue;
+            if constexpr (PREC == 3) {
+                float r[4] = {hreg[it][0], hreg[it][1], hreg[it][2], hreg[it][3]};
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    bf16x4 q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const __bf16 hq = (__bf16)r[e];
+                        q[e] = hq;
+                        if (pl < 2) r[e] = r[e] - (float)hq;
+                    }
+                    *(bf16x4*)(halo + pl * HALO_PLANE + h_lds[it]) = q;
+                }
+            } else {
+                *(f32x4*)(halo + h_lds[it]) = hreg[it];
+            }
+        }
+    };
+
+    // ---- weight staging (LDS-DMA, as conv3d_f32_kernel): one k-tile = (tap, 32 input channels)
+    const int srow = lane >> 3, pchunk = lane & 7;
+    const float* w_src[W_INSTR];
+    int w_dst[W_INSTR];
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i) {
+        const int pi = i * NW + wave;
+        if constexpr (PREC == 3) {
+            const int plane = pi / (BN / 16), rblk = pi % (BN / 16);
+            const int row = rblk * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3);
+            w_dst[i] = plane * (BN * 64) + rblk * 1024;
+            w_src[i] = p.w + ((long)min(n0 + row, p.Cout - 1) * (K / 32) * 48 + plane * 16 + chunk * 4);
+        } else {
+            const int row = pi * 8 + srow;
+            w_dst[i] = pi * 1024;
+            w_src[i] = p.w + (long)min(n0 + row, p.Cout - 1) * K + (pchunk ^ ((row >> 1) & 7)) * 4;
+        }
+    }
+    // (the source operand is cast to const void*: given a `const float*` rvalue here, hipcc's host pass silently drops the kernel's
+    // launch stub from the object - undefined symbol at load time)
+#define UV_HALO_STAGE_W(G, TAP, BUF)                                                                                        \
+    do {                                                                                                                    \
+        const int dt_ = (G) / ncb, cb_ = (G) - dt_ * ncb;                                                                    \
+        const int ktile_ = (dt_ * 9 + (TAP)) * ncb + cb_;      /* k order of the weight matrix: tap-major, channels minor */ \
+        const int koff_ = ktile_ * (PREC == 3 ? 48 : 32);                                                                   \
+        _Pragma("unroll") for (int i = 0; i < W_INSTR; ++i)                                                                 \
+            __builtin_amdgcn_global_load_lds((const void*)(w_src[i] + koff_), (lds_void_h*)(wbuf + (BUF) * W_BYTES + w_dst[i]), 16, 0, 0);  \
+    } while (0)
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    int hpb[TM];                 // halo pixel of this lane's output pixel of fragment j for tap (0, 0)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) hpb[j] = (wm * 2 + (j >> 1)) * HW_ + (j & 1) * 16 + frow;
+    int w_off[TN], w_key[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int row = wn * 64 + i * 16 + frow;
+        if constexpr (PREC == 3) {
+            w_off[i] = row * 64 + ((fq ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3)) << 4);
+            w_key[i] = 0;
+        } else {
+            w_off[i] = row * 128;
+            w_key[i] = (row >> 1) & 7;
+        }
+    }
+
+    auto compute = [&](int tap, const char* wb) __attribute__((always_inline)) {
+        const int dh = tap / 3, dw = tap - dh * 3;
+        const int toff = dh * HW_ + dw;
+        if constexpr (PREC == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f32x4 af[TM], wf[TN];
+                const int c = ks * 4 + fq;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int hp = hpb[j] + toff;
+                    af[j] = *(const f32x4*)(halo + hp * 128 + ((c ^ ((hp >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i) wf[i] = *(const f32x4*)(wb + w_off[i] + ((c ^ w_key[i]) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < TM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], af[j][e], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            bf16x8 ap[TM][3], wp[TN][3];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int hp = hpb[j] + toff;
+                const int o = hp * 64 + ((fq ^ ((0x1320 >> (4 * ((hp >> 2) & 3))) & 3)) << 4);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) ap[j][pl] = *(const bf16x8*)(halo + pl * HALO_PLANE + o);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wp[i][pl] = *(const bf16x8*)(wb + w_off[i] + pl * (BN * 64));
+            // the six terms with plane(i) + plane(j) <= 2, smallest first (conv3d_f32_kernel PREC 3: same order, same values)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][2], ap[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][1], ap[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][0], ap[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][1], ap[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][0], ap[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[i][0], ap[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- pipeline: halo of group g+1 in registers while the nine taps of group g run; weights double-buffered per tap
+    load_halo(0);
+    UV_HALO_STAGE_W(0, 0, 0);
+    write_halo();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        const bool more = g + 1 < ngroups;
+        if (more) load_halo(g + 1);
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) UV_HALO_STAGE_W(g, tap + 1, buf ^ 1);
+            else if (more) UV_HALO_STAGE_W(g + 1, 0, buf ^ 1);
+            compute(tap, wbuf + buf * W_BYTES);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (more) {             // every wave has left the halo image of group g behind (barrier above)
+            write_halo();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias, optional residual, f32 store (pixel m = (frame, y, x) of the output tensor)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int py = wm * 2 + (j >> 1), px = (j & 1) * 16 + frow;
+        const int y = ty0 + py, x = tx0 + px;
+        if (y >= p.Hout || x >= p.Wout) continue;
+        const long m = ((long)tf * p.Hout + y) * p.Wout + x;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + 4 * fq;
+            if (n >= p.Cout) continue;
+            f32x4 v = acc[i][j];
+            if (p.bias) {
+                const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += b[e];
+            }
+            if (p.resid) {
+                const f32x4 rr = *(const f32x4*)(p.resid + m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rr[e];
+            }
+            *(f32x4*)(p.out + m * p.ldo + n) = v;
+        }
+    }
+}
+
+
+// Which convolutions take the halo kernel: 3x3 spatial taps, stride 1, padding 1, no upsampling / interleave, whole 32-channel input
+// blocks (all callers pad), at least one full 128-wide output-channel tile, and enough tiles to fill the chip.
+// UV_CONV_HALO in the environment (developer A/B knob and test hook, read per call): "0" = never, "1" = whenever the geometry fits
+// (also launches too small to fill the chip, which the tests use), unset = automatic.
+bool uv_conv3d_halo_eligible(const ConvArgs& a, int prec) {
+    const char* e = getenv("UV_CONV_HALO");
+    if (e && e[0] == '0') return false;
+    if (!(prec == 0 || prec == 3)) return false;
+    if (a.kh != 3 || a.kw != 3 || (a.kt != 3 && a.kt != 1)) return false;
+    if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.up || a.interleave) return false;
+    if (a.Hin != a.Hout || a.Win != a.Wout || a.Cout % 128 != 0 || a.Cin % 32 != 0) return false;
+    const long tiles = (long)a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * (a.Cout / 128);
+    return (e && e[0] == '1') || tiles >= uv_num_cus();
+}
+
+int uv_launch_conv3d_halo(ConvArgs& a, int prec, hipStream_t stream) {
+    a.tiles_n = a.Cout / 128;
+    a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
+    const size_t lds = prec == 3 ? 3 * 344 * 64 + 2 * 128 * 192 : 344 * 128 + 2 * 128 * 128;
+    static bool attr_set[UV_MAX_DEV][2];
+    bool& attr = attr_set[uv_cur_dev()][prec == 3];
+    if (prec == 3) {
+        if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(conv3d_halo_kernel<3>, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+    } else {
+        if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(conv3d_halo_kernel<0>, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+    }
+    attr = true;
+    return 0;
+}

@@ -1,0 +1,21 @@
+// Argument block of the VAE convolution kernels (conv3d_f32.hip: gather kernel, every geometry; conv3d_halo.hip: LDS-halo kernel for
+// the 3x3(x3) stride-1 convolutions).
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    const float* in;     // [Tin, Hin, Win, ld_in] channels-last
+    const float* w;      // [Cout, taps * Cin]
+    const float* bias;   // [Cout] or nullptr
+    const float* resid;  // [M, ldr] or nullptr
+    float* out;
+    const float* zeros;
+    long ld_in, ldo, ldr;
+    int Tout, Hout, Wout, Tin, Hin, Win;
+    int Cin, Cout, kt, kh, kw, st, sh, sw, t_off, ph, pw, up, interleave;
+    int M, tiles_m, tiles_n;
+};
+
+// conv3d_halo.hip
+bool uv_conv3d_halo_eligible(const ConvArgs& a, int prec);
+int uv_launch_conv3d_halo(ConvArgs& a, int prec, hipStream_t stream);
