@@ -33,7 +33,6 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
     constexpr int W_PIECES = W_BYTES / 1024, W_INSTR = W_PIECES / NW;            // 16 / 24 pieces -> 2 / 3 per wave
     constexpr int NLD = 6;                                                      // 340 x 8 sixteen-byte chunks over 512 lanes
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const halo = smem;
     char* const wbuf = smem + HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
             hreg[it] = *(const f32x4*)(ok ? base + h_off[it] : p.zeros);
         }
     };
-    auto write_halo = [&]() __attribute__((always_inline)) {
+    auto write_halo = [&](char* halo) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             if (h_lds[it] == 0xffffffffu) continue;
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
         }
     }
 
-    auto compute = [&](int tap, const char* wb) __attribute__((always_inline)) {
+    auto compute = [&](int tap, const char* wb, const char* halo) __attribute__((always_inline)) {
         const int dh = tap / 3, dw = tap - dh * 3;
         const int toff = dh * HW_ + dw;
         if constexpr (PREC == 0) {
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
     // ---- pipeline: halo of group g+1 in registers while the nine taps of group g run; weights double-buffered per tap
     load_halo(0);
     UV_HALO_STAGE_W(0, 0, 0);
-    write_halo();
+    write_halo(smem);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
@@ -220,13 +219,13 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
         for (int tap = 0; tap < 9; ++tap) {
             if (tap < 8) UV_HALO_STAGE_W(g, tap + 1, buf ^ 1);
             else if (more) UV_HALO_STAGE_W(g + 1, 0, buf ^ 1);
-            compute(tap, wbuf + buf * W_BYTES);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            compute(tap, wbuf + buf * W_BYTES, smem);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();
             buf ^= 1;
         }
-        if (more) {             // every wave has left the halo image of group g behind (barrier above)
-            write_halo();
+        if (more) {   // every wave has left the halo image of group g behind (barrier above)
+            write_halo(smem);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -261,18 +260,24 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
 
 
 // Which convolutions take the halo kernel: 3x3 spatial taps, stride 1, padding 1, no upsampling / interleave, whole 32-channel input
-// blocks (all callers pad), at least one full 128-wide output-channel tile, and enough tiles to fill the chip.
+// blocks (all callers pad), whole 128-wide output-channel tiles, and enough tiles per frame to fill the chip at four frames per pass.
 // UV_CONV_HALO in the environment (developer A/B knob and test hook, read per call): "0" = never, "1" = whenever the geometry fits
 // (also launches too small to fill the chip, which the tests use), unset = automatic.
 bool uv_conv3d_halo_eligible(const ConvArgs& a, int prec) {
     const char* e = getenv("UV_CONV_HALO");
     if (e && e[0] == '0') return false;
     if (!(prec == 0 || prec == 3)) return false;
+    // exact f32 runs on the halo kernel only when asked to (tests; A/B): its MFMA is 16x slower than the bf16 one, the gather kernel is
+    // already matrix-pipe-bound there (83 % of the f32 MFMA peak), and two independent 4-wave workgroups per CU hide its barrier stalls
+    // better than this kernel's one 8-wave workgroup: measured 6.49 s (halo) against 6.40 s (gather) per 49 x 720 x 1280 decode.
+    if (prec == 0 && !(e && e[0] == '1')) return false;
     if (a.kh != 3 || a.kw != 3 || (a.kt != 3 && a.kt != 1)) return false;
     if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.up || a.interleave) return false;
     if (a.Hin != a.Hout || a.Win != a.Wout || a.Cout % 128 != 0 || a.Cin % 32 != 0) return false;
-    const long tiles = (long)a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * (a.Cout / 128);
-    return (e && e[0] == '1') || tiles >= uv_num_cus();
+    // per-FRAME tile count: the choice must not depend on how many frames a pass carries (the pass length is a memory / speed knob
+    // that leaves results bit-identical, and the two kernels sum their k-tiles in different orders)
+    const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * (a.Cout / 128);
+    return (e && e[0] == '1') || 4 * tiles >= uv_num_cus();
 }
 
 int uv_launch_conv3d_halo(ConvArgs& a, int prec, hipStream_t stream) {

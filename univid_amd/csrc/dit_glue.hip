@@ -8,6 +8,7 @@
 //   patch_embedding im2col / unpatchify   model.py:448-451, 499-522
 //   sinusoidal_embedding_1d + time MLPs   model.py:14-24, 384-386, 460-469
 #include "common.h"
+#include <type_traits>
 #ifndef UV_LN_NT
 #define UV_LN_NT 1
 #endif
@@ -34,13 +35,19 @@ struct LnArgs {
 // A 4-wave block walks 4*RPW consecutive token rows, one row per wave at a time. The modulation (or affine) parameters of
 // the block's first row are staged in LDS once and read from there by every row with the same table index (the usual
 // case: a sample's tokens share one timestep); the parameter reads are otherwise 2x the x reads in load instructions.
-template <int MAXV, int RPW>
+// EXACT: C == MAXV * 256, every lane owns MAXV float4 chunks: no per-chunk predicates, so a row's loads are ONE burst behind ONE wait
+// (behind the `i < nv` predicates hipcc emitted a load and an s_waitcnt vmcnt(0) per chunk: twelve dependent HBM round trips per row).
+// SMODE >= 0: the mode is a compile-time constant, the output is bf16 and the normalised value is not rounded before the modulation (the
+// DiT's per-block calls): the output pass is straight-line code - with mode / output type / rounding as run-time branches inside the
+// chunk loop every chunk was its own basic block with its own waits.
+template <int MAXV, int RPW, bool EXACT = false, int SMODE = -1>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(LnArgs p) {
+    if constexpr (SMODE >= 0) { p.mode = SMODE; p.out_bf16 = 1; p.round_ln = 0; }
     extern __shared__ __attribute__((aligned(16))) char ln_smem[];
     f32x4* sp = (f32x4*)ln_smem;                 // [2][nv*64]: scale|shift (mode 1) or w|b (mode 2)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int nv = p.C >> 8;                      // float4 per lane
+    const int nv = EXACT ? MAXV : p.C >> 8;       // float4 per lane
     const int brow0 = blockIdx.x * 4 * RPW;
     int t_blk = 0;
     if (p.mode != 0) {
@@ -67,7 +74,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(LnArgs p) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i)
-            if (i < nv) {
+            if (EXACT || i < nv) {
                 v[i] = UV_LN_NT ? __builtin_nontemporal_load((const f32x4*)(xr + (i * 64 + lane) * 4)) : *(const f32x4*)(xr + (i * 64 + lane) * 4);
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(LnArgs p) {
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i)
-            if (i < nv) {
+            if (EXACT || i < nv) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d = v[i][e] - mean;
@@ -88,45 +95,52 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(LnArgs p) {
             }
         const float var = wave_sum(q) / (float)p.C;
         const float rstd = 1.0f / sqrtf(var + p.eps);
+        // the output pass, once per parameter source: with the LDS / global choice INSIDE the chunk loop every chunk carried a possible
+        // global load, and hipcc waited vmcnt(0) - i.e. for the previous chunk's STORE - in front of each one
+        auto emit = [&](auto lds_tag) __attribute__((always_inline)) {
+            constexpr bool FROM_LDS = decltype(lds_tag)::value;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i)
-            if (i < nv) {
-                const int c = (i * 64 + lane) * 4;
-                f32x4 y;
+            for (int i = 0; i < MAXV; ++i)
+                if (EXACT || i < nv) {
+                    const int c = (i * 64 + lane) * 4;
+                    f32x4 y;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float tt = __fmul_rn(v[i][e] - mean, rstd);
-                    if (p.round_ln) tt = round_bf(tt);
-                    y[e] = tt;
-                }
-                if (p.mode != 0) {
-                    f32x4 pa, pb;
-                    if (from_lds) {
-                        pa = sp[i * 64 + lane];
-                        pb = sp[nv * 64 + i * 64 + lane];
-                    } else {
-                        pa = *(const f32x4*)(scale + c);
-                        pb = *(const f32x4*)(shift + c);
+                    for (int e = 0; e < 4; ++e) {
+                        float tt = __fmul_rn(v[i][e] - mean, rstd);
+                        if (p.round_ln) tt = round_bf(tt);
+                        y[e] = tt;
                     }
-                    if (p.mode == 1) {
+                    if (p.mode != 0) {
+                        f32x4 pa, pb;
+                        if constexpr (FROM_LDS) {
+                            pa = sp[i * 64 + lane];
+                            pb = sp[nv * 64 + i * 64 + lane];
+                        } else {
+                            pa = *(const f32x4*)(scale + c);
+                            pb = *(const f32x4*)(shift + c);
+                        }
+                        if (p.mode == 1) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], __fadd_rn(1.0f, pa[e])), pb[e]);
+                            for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], __fadd_rn(1.0f, pa[e])), pb[e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], pa[e]), pb[e]);
+                        }
+                    }
+                    if (p.out_bf16 == 2) {   // IEEE fp16 output (SigLIP2 ranker in its reference dtype)
+                        u32x2 o = {pack16_2<true>(y[0], y[1]), pack16_2<true>(y[2], y[3])};
+                        *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;
+                    } else if (p.out_bf16) {
+                        u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+                        if (UV_LN_NT) __builtin_nontemporal_store(o, (u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c));
+                        else *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;
                     } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(__fmul_rn(y[e], pa[e]), pb[e]);
+                        *(f32x4*)((float*)p.out + (long)row * p.ldo + c) = y;
                     }
                 }
-                if (p.out_bf16 == 2) {   // IEEE fp16 output (SigLIP2 ranker in its reference dtype)
-                    u32x2 o = {pack16_2<true>(y[0], y[1]), pack16_2<true>(y[2], y[3])};
-                    *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;
-                } else if (p.out_bf16) {
-                    u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-                    if (UV_LN_NT) __builtin_nontemporal_store(o, (u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c));
-                    else *(u32x2*)((bf16_t*)p.out + (long)row * p.ldo + c) = o;
-                } else {
-                    *(f32x4*)((float*)p.out + (long)row * p.ldo + c) = y;
-                }
-            }
+        };
+        if (from_lds) emit(std::true_type{});
+        else emit(std::false_type{});
     }
 }
 
@@ -147,7 +161,13 @@ extern "C" int uv_layernorm_mod(const float* x, long ldx, void* out, long ldo, i
     const dim3 grid((L + 3) / 4), block(256);
     const size_t lds = mode == 0 ? 0 : (size_t)2 * (C / 4) * 16;
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 1024) hipLaunchKernelGGL((layernorm_mod_kernel<4, 1>), grid, block, lds, st, a);
+    const bool plain_bf16 = out_bf16 == 1 && !round_ln;
+    if (C == 3072 && plain_bf16 && mode == 1) hipLaunchKernelGGL((layernorm_mod_kernel<12, 1, true, 1>), grid, block, lds, st, a);   // the DiT:
+    else if (C == 3072 && plain_bf16 && mode == 2) hipLaunchKernelGGL((layernorm_mod_kernel<12, 1, true, 2>), grid, block, lds, st, a);   // AdaLN / norm3
+    else if (C == 3072) hipLaunchKernelGGL((layernorm_mod_kernel<12, 1, true>), grid, block, lds, st, a);
+    else if (C == 768) hipLaunchKernelGGL((layernorm_mod_kernel<3, 1, true>), grid, block, lds, st, a);       // the SigLIP2 towers
+    else if (C == 1024) hipLaunchKernelGGL((layernorm_mod_kernel<4, 1, true>), grid, block, lds, st, a);
+    else if (C <= 1024) hipLaunchKernelGGL((layernorm_mod_kernel<4, 1>), grid, block, lds, st, a);
     else if (C <= 3072) hipLaunchKernelGGL((layernorm_mod_kernel<12, 1>), grid, block, lds, st, a);
     else if (C <= 4096) hipLaunchKernelGGL((layernorm_mod_kernel<16, 1>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((layernorm_mod_kernel<32, 1>), grid, block, lds, st, a);
