@@ -1134,8 +1134,11 @@ def test_dit_trained_weight_regime_stress_vs_oracle():
                        name="trained-weight regime, 3-block forward output")
 
 
-# (min inside fraction, max |err| / range): 1.5 x what MI355X measured (profiles/r03_parity_margins.json)
-STRESS_GATE = {1: (0.0, 1.0), 3: (0.0, 1.0), "out": (0.0, 1.0)}
+# (min inside fraction, max |err| / range). Measured on MI355X (profiles/r03_parity_margins.json): in this regime the bf16 roundings of BOTH
+# implementations are amplified (rms distance to the no-rounding truth 0.046 / 0.24 / 0.041 for the oracle, 0.9997 / 0.9952 / 0.9954 of
+# that for the HIP path), so only 21 % / 3.6 % / 4.3 % of the elements agree to rtol 1e-3 / atol 1e-4 and the gate that carries the test
+# is the truth ratio (<= 1.02); max error 4.4e-3 / 1.5e-2 / 2.1e-2 of the range, gates = x 1.5.
+STRESS_GATE = {1: (0.10, 6.6e-3), 3: (0.0, 2.3e-2), "out": (0.0, 3.2e-2)}
 
 
 def test_vae_heavy_tailed_input_stress_vs_oracle():
