@@ -51,6 +51,7 @@ struct GemmArgs {
     long lda, ldw, ldo, gate_stride;
     int M, N, K;
     int tiles_m, tiles_n;
+    int gm;                   // persistent kernel: height (in tiles) of the column groups the tile walk is made of
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_persist_kernel(GemmArgs p) 
     }
     int cur = blockIdx.x >> 3;
     if (cur >= cnt) return;
-    constexpr int GM = 4;
+    const int GM = p.gm;
     const int group_sz = GM * p.tiles_n;
     auto origin = [&](int bid, int& m0, int& n0) {
         const int group = bid / group_sz;
@@ -923,6 +924,10 @@ static int launch_8ph_persist(const GemmArgs& a0, int epi, hipStream_t stream) {
                  "uv_gemm_bf16_nt: the persistent kernel stores 16 bytes per lane: ldo=%ld must be a multiple of 8 elements", a.ldo);
     a.tiles_m = a.M / 256;
     a.tiles_n = a.N / 256;
+    // height of the tile walk's column groups (same-process A/B on the DiT shapes, tools/gemm_gm_ab.py: N = K = 3072 325 -> 319 us at 8,
+    // N = 14336 best at 4, K = 14336 1438 -> 1428 us at 2; the results do not depend on it)
+    a.gm = (a.N <= 4096 && a.K <= 4096) ? 8 : (a.K >= 8192 ? 2 : 4);
+    if (const char* e = getenv("UV_GEMM_GM")) a.gm = atoi(e) > 0 ? atoi(e) : a.gm;    // developer A/B knob
     const int tiles = a.tiles_m * a.tiles_n;
     int wgs = uv_num_cus() & ~7;
     if (wgs > tiles) wgs = tiles & ~7;
