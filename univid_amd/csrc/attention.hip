@@ -33,6 +33,18 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// tools/diag/attn_timeline.hip builds this file with -DUV_ATTN_TIMELINE: 100 MHz wall-clock stamps per workgroup at the phase
+// boundaries of flash_attn_fwd3_kernel / flash_attn_fwd12_kernel plus the hardware id of the CU it ran on. Compiled out of the library.
+#ifdef UV_ATTN_TIMELINE
+__device__ unsigned long long* uv_attn_tl;
+#define UV_TL(id, slot) do { if (threadIdx.x == 0) uv_attn_tl[(size_t)(id) * 8 + (slot)] = wall_clock64(); } while (0)
+#define UV_TL_HW(id) do { if (threadIdx.x == 0) { unsigned hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); uv_attn_tl[(size_t)(id) * 8 + 7] = ((unsigned long long)xcc_ << 32) | hw_; } } while (0)
+#else
+#define UV_TL(id, slot) do {} while (0)
+#define UV_TL_HW(id) do {} while (0)
+#endif
+
 #define UV_ATTN_LONG_DEFAULT_PW4 false
 
 typedef __attribute__((address_space(3))) void lds_void_a;
@@ -391,6 +403,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     const int q0w = qb * (NW * UV_ATT_QW) + wave_u * UV_ATT_QW;
     const long hcol = (long)head * D;
+    UV_TL(vb, 0);
+    UV_TL_HW(vb);
 
     bf16x8 qf[NKK];
     {
@@ -471,6 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(vaddr[i >> 1][i & 1]));
     asm volatile("" : "+v"(koff), "+v"(voff));
     __syncthreads();
+    UV_TL(vb, 1);
 
     // One staged tile = 64 keys = two 32-key halves that are computed one after the other (QK, softmax, PV per half): the S
     // accumulator of only one half is live beside O and Q, which is what leaves registers for fragment reads ahead of their
@@ -600,6 +615,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         else tile(nt_full, T_{}, F{}, P0{});
     }
 
+    UV_TL(vb, 2);
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0w + r;
@@ -614,6 +630,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 *(u32x2*)(op + 32 * d + 8 * g) = o;
             }
     }
+    UV_TL(vb, 3);
+#ifdef UV_ATTN_TIMELINE_DRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    UV_TL(vb, 4);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -677,6 +698,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const bool compute_wave = wave_u < min(units, nwu - u0);      // the head's last block may be ragged
     const int q0w = (u0 + wave_u) * UV_ATT_QW;
     const long hcol = (long)head * D;
+    UV_TL(blockIdx.x, 0);
+    UV_TL_HW(blockIdx.x);
 
     bf16x8 qf[NKK];
     {
@@ -759,6 +782,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(vaddr[i >> 1][i & 1]));
     asm volatile("" : "+v"(koff), "+v"(voff));
     __syncthreads();
+    UV_TL(blockIdx.x, 1);
 
     if (!compute_wave) {
         // loader-only wave: its share of every tile's LDS-DMA pieces and every barrier, nothing else
@@ -883,6 +907,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         else tile(nt_full, T_{}, F{}, P0{});
     }
 
+    UV_TL(blockIdx.x, 2);
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0w + r;
@@ -897,6 +922,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 *(u32x2*)(op + 32 * d + 8 * g) = o;
             }
     }
+    UV_TL(blockIdx.x, 3);
+#ifdef UV_ATTN_TIMELINE_DRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    UV_TL(blockIdx.x, 4);
+#endif
 }
 
 // ---- kernel selection: the ONE place that decides which kernel serves a call ------------------------------------------------
