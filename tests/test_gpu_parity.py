@@ -1828,7 +1828,7 @@ def test_conv3d_halo_kernel_geometries(entry, monkeypatch):
     from univid_amd import _lib
     g = torch.Generator().manual_seed(14)
 
-    def run(x_cl, w, b, Tout, Hout, Wout, halo, resid=None, t_off=0):
+    def run(x_cl, w, b, Tout, Hout, Wout, halo, resid=None, t_off=0, up=0):
         monkeypatch.setenv("UV_CONV_HALO", "1" if halo else "0")
         T, H, W, C = x_cl.shape
         co, ci, kt, kh, kw_ = w.shape
@@ -1837,10 +1837,20 @@ def test_conv3d_halo_kernel_geometries(entry, monkeypatch):
             wp = _split6(wp)
         out = torch.full((Tout, Hout, Wout, co), 7.0, device=DEV)
         _lib.call(entry, _lib.ptr(x_cl), C, T, H, W, _lib.ptr(wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), co, Tout, Hout, Wout, C, co,
-                  kt, kh, kw_, 1, 1, 1, t_off, 1, 1, 0, 0, _lib.ptr(resid), 0 if resid is None else co, _lib.stream_ptr())
+                  kt, kh, kw_, 1, 1, 1, t_off, 1, 1, up, 0, _lib.ptr(resid), 0 if resid is None else co, _lib.stream_ptr())
         return out.cpu()
 
     cl = lambda t: t[0].permute(1, 2, 3, 0).contiguous().to(DEV)
+    # Resample's nearest-exact 2x + Conv2d 3x3 (vae2_2.py:86-96, 153-155): the halo image is filled through the upsampling map
+    for (T, H, W, ci, co) in ((2, 9, 13, 64, 128), (3, 20, 35, 32, 256)):
+        x = torch.randn(1, ci, T, H, W, generator=g)
+        w, b = torch.randn(co, ci, 1, 3, 3, generator=g) * 0.05, torch.randn(co, generator=g)
+        up = F.interpolate(x[0].permute(1, 0, 2, 3), scale_factor=(2.0, 2.0), mode="nearest-exact").permute(1, 0, 2, 3)[None]
+        ref = F.conv3d(F.pad(up, (1, 1, 1, 1)), w, b)[0].permute(1, 2, 3, 0)
+        got = run(cl(x), w, b, T, 2 * H, 2 * W, True, up=1)
+        old = run(cl(x), w, b, T, 2 * H, 2 * W, False, up=1)
+        assert_f32_close(got.permute(3, 0, 1, 2), ref.permute(3, 0, 1, 2), rtol=1e-4, atol=1e-4, name=f"halo up {entry} {T}x{H}x{W} {ci}->{co}")
+        assert (got - old).abs().max() <= 1e-5 * max(1.0, float(old.abs().max()))
     for (T, H, W, ci, co, kt) in ((3, 19, 23, 64, 128, 3), (2, 8, 32, 32, 256, 3), (2, 40, 70, 64, 128, 3), (4, 16, 64, 96, 128, 1)):
         x = torch.randn(1, ci, T, H, W, generator=g)
         w, b = torch.randn(co, ci, kt, 3, 3, generator=g) * 0.05, torch.randn(co, generator=g)

@@ -3,7 +3,8 @@
 //
 // Replaces (reference, fp32 nn.Conv3d through cuDNN): CausalConv3d.forward  models/wan/utils/modules/vae2_2.py:17-42 as used by
 // ResidualBlock (vae2_2.py:193-235); same arithmetic contract as conv3d_f32_kernel (conv3d_f32.hip), which keeps every other
-// geometry (1x1x1, strided, 2x-upsampling, time_conv, Cout not a multiple of 16 x 8).
+// geometry (1x1x1, strided, time_conv, Cout not a multiple of 16 x 8). Resample's "nearest-exact 2x + Conv2d 3x3" (vae2_2.py:86-96,
+// 153-155) runs here too: the halo image is filled through the upsampling map, the MFMA loop does not know.
 //
 // conv3d_f32_kernel gathers a 128-pixel x 32-channel A tile from L2 for EVERY tap (27 gathers of the same pixels per channel block).
 // Here a workgroup owns an 8 x 32 pixel patch of one frame and stages, once per (input frame dt, 32-channel block), the patch with
@@ -57,10 +58,12 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
     for (int it = 0; it < NLD; ++it) {
         const int s = it * 512 + tid, hp = s >> 3, ch = s & 7;
         const int hy = hp / HW_, hx = hp - hy * HW_;
-        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
-        const bool ok = hp < NHP && (unsigned)y < (unsigned)p.Hin && (unsigned)x < (unsigned)p.Win;
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;                          // coordinates of the convolution's input image
+        const bool ok = hp < NHP && (unsigned)y < (unsigned)p.Hout && (unsigned)x < (unsigned)p.Wout;
         h_ok |= (unsigned)ok << it;
-        h_off[it] = ok ? ((long)y * p.Win + x) * p.ld_in + ch * 4 : 0;
+        // up: that image is the nearest-exact 2x upsampling of the stored one (vae2_2.py:86-96): pixel (y, x) <- (y >> 1, x >> 1)
+        const int sy = p.up ? y >> 1 : y, sx = p.up ? x >> 1 : x;
+        h_off[it] = ok ? ((long)sy * p.Win + sx) * p.ld_in + ch * 4 : 0;
         if constexpr (PREC == 3) h_lds[it] = hp * 64 + ((((ch >> 1) ^ ((0x1320 >> (4 * ((hp >> 2) & 3))) & 3)) << 4) | ((ch & 1) << 3));
         else h_lds[it] = hp * 128 + ((ch ^ ((hp >> 1) & 7)) << 4);
         if (hp >= 344) h_lds[it] = 0xffffffffu;                                // beyond the padded image: never written
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
 }
 
 
-// Which convolutions take the halo kernel: 3x3 spatial taps, stride 1, padding 1, no upsampling / interleave, whole 32-channel input
+// Which convolutions take the halo kernel: 3x3 spatial taps, stride 1, padding 1 (plain or behind the 2x upsampling), no interleave, whole 32-channel input
 // blocks (all callers pad), whole 128-wide output-channel tiles, and enough tiles per frame to fill the chip at four frames per pass.
 // UV_CONV_HALO in the environment (developer A/B knob and test hook, read per call): "0" = never, "1" = whenever the geometry fits
 // (also launches too small to fill the chip, which the tests use), unset = automatic.
@@ -272,8 +275,9 @@ bool uv_conv3d_halo_eligible(const ConvArgs& a, int prec) {
     // better than this kernel's one 8-wave workgroup: measured 6.49 s (halo) against 6.40 s (gather) per 49 x 720 x 1280 decode.
     if (prec == 0 && !(e && e[0] == '1')) return false;
     if (a.kh != 3 || a.kw != 3 || (a.kt != 3 && a.kt != 1)) return false;
-    if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.up || a.interleave) return false;
-    if (a.Hin != a.Hout || a.Win != a.Wout || a.Cout % 128 != 0 || a.Cin % 32 != 0) return false;
+    if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.interleave) return false;
+    const int mul = a.up ? 2 : 1;                            // up: the halo image is filled through the 2x nearest-exact map
+    if (a.Hin * mul != a.Hout || a.Win * mul != a.Wout || a.Cout % 128 != 0 || a.Cin % 32 != 0) return false;
     // per-FRAME tile count: the choice must not depend on how many frames a pass carries (the pass length is a memory / speed knob
     // that leaves results bit-identical, and the two kernels sum their k-tiles in different orders)
     const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * (a.Cout / 128);
