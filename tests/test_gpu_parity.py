@@ -922,6 +922,45 @@ def test_dit_block_ti2v5b_width_1014_tokens_vs_oracle():
     assert_model_close(xs, ref[0], truth[0], frac=0.77, max_rel=2.7e-3, name="TI2V-5B block, L=1014")   # measured 84.7 %, 1.7e-3, 1.0003
 
 
+def test_dit_block_ti2v5b_width_full_length_vs_cpu_oracle():
+    """The bench's own shape against the PINNED oracle, not against oracle text run by torch-ROCm eager: one TI2V-5B-width block at
+    L = 13 x 22 x 40 = 11 440 tokens (the 49-frame 704 x 1280 latent: the long-key attention kernel with its 12- / 8-unit blocks, the
+    persistent GEMM with its leftover-row launch, every glue kernel at its full-size instantiation), two distinct timesteps, against
+    oracle/wan_dit.block_forward on the host cores (about 4 s per run on 32 threads) and its no-rounding truth run."""
+    from oracle import wan_dit
+    from univid_amd import detinit
+    from univid_amd.wan.model import WanAttentionBlock, _freqs_device, rope_params
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    dim, ffn, heads, grid = 3072, 14336, 24, (13, 22, 40)
+    Lt = grid[0] * grid[1] * grid[2]
+    with torch.device(DEV):
+        blk = WanAttentionBlock(dim, ffn, heads, (-1, -1), True, True, 1e-6)
+    sd = {"blocks.0." + k: v for k, v in blk.state_dict(keep_vars=True).items()}
+    detinit.init_state_dict_(sd, 12)
+    blk.eval()
+    sdc = {k: v.detach().cpu() for k, v in sd.items()}
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(1, Lt, dim, generator=g)
+    e_rows = torch.randn(2, 6, dim, generator=g) * 0.3
+    tid = (torch.arange(Lt) >= grid[1] * grid[2]).long()              # first latent frame at its own timestep (i2v)
+    ctx = (torch.randn(1, 512, dim, generator=g) * 0.5).to(BF16)
+    d = dim // heads
+    freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)), rope_params(1024, 2 * (d // 6))], dim=1)
+    e0 = e_rows[tid].unsqueeze(0)
+    with torch.no_grad():
+        ref = wan_dit.block_forward(sdc, "blocks.0.", x, e0, torch.tensor([Lt]), torch.tensor([grid]), freqs, ctx, heads, 1e-6)
+        old, wan_dit.BF16 = wan_dit.BF16, torch.float32
+        try:
+            truth = wan_dit.block_forward(sdc, "blocks.0.", x, e0, torch.tensor([Lt]), torch.tensor([grid]), freqs, ctx.float(), heads, 1e-6)
+        finally:
+            wan_dit.BF16 = old
+        xs = x[0].to(DEV).clone()
+        blk.prepare()
+        blk._run(xs, Lt, e_rows.reshape(2, -1).to(DEV), tid.to(torch.int32).to(DEV), grid, _freqs_device(freqs, torch.device(DEV)),
+                 ctx[0].to(DEV), first_block=False)
+    assert_model_close(xs, ref[0], truth[0], frac=0.79, max_rel=4.3e-3, name="TI2V-5B block, L=11440 (CPU oracle)")   # measured 86.2 %, 2.8e-3, 1.0008
+
+
 def SAMPLER10_GATE(what):
     # 10 steps take 5x larger steps than 50. Measured on MI355X (profiles/r02_parity_margins.json): noise_pred 1.9e-3 (step 0) ->
     # 3.3e-3 (step 9), latents 1.4e-5 -> 5.2e-4. Gates = 1.5 x the largest measured value.
