@@ -1103,6 +1103,50 @@ def test_dit_stack_ti2v5b_width_depth_vs_oracle():
                        name="TI2V-5B width, 8-block forward output (L=520)")
 
 
+# measured on MI355X (profiles/r03_parity_margins.json): inside 94.6 / 87.6 / 75.7 / 53.1 %, max error 3.8e-3 / 3.9e-3 / 3.8e-3 / 9.7e-4 of the
+# range, rms-vs-truth ratio 0.9995-1.0000; gates = 1.5 x the measured outside fraction / maximum
+FULL_LENGTH_GATE = {1: (0.919, 5.7e-3), 2: (0.814, 5.9e-3), 4: (0.636, 5.7e-3), "out": (0.296, 1.5e-3)}
+
+
+def test_dit_stack_full_length_vs_cpu_oracle():
+    """DEPTH at the bench's own length against the PINNED oracle: a 4-block stack at TI2V-5B width and L = 13 x 22 x 40 = 11 440 tokens
+    (two timesteps, 77-row prompt) through WanModel.forward - patch embedding, time embedding, text embedding, blocks, head,
+    unpatchify - against oracle/wan_dit.dit_forward on the host cores and its no-rounding truth run (the 30-block full-length run is
+    compared with the oracle text on torch-ROCm eager, test_real_shapes_vs_eager_oracle; this one ties the same shape to the CPU)."""
+    from oracle import wan_dit
+    from univid_amd.wan.model import WanModel
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    cfg = dict(wan_dit.TI2V_5B_CFG, num_layers=4)
+    with torch.device(DEV):
+        m = WanModel.from_config(dict(cfg, model_type="ti2v"))
+    m = m.eval().requires_grad_(False)
+    m.init_weights(29)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    grid = (13, 22, 40)
+    Lt = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(37)
+    x = torch.randn(48, grid[0], 2 * grid[1], 2 * grid[2], generator=g)
+    ctx = [torch.randn(77, cfg["text_dim"], generator=g) * 0.1]
+    t = torch.full((1, Lt), 812.0)
+    t[0, :grid[1] * grid[2]] = 0.0                                   # i2v: first latent frame at timestep 0
+    hidden = []
+    for blk in m.blocks:
+        def run(xs, *a, _orig=blk._run, **kw):
+            _orig(xs, *a, **kw)
+            hidden.append(xs.clone())
+        blk._run = run
+    with torch.no_grad():
+        out = m([x.to(DEV)], t.to(DEV), [c.to(DEV) for c in ctx], Lt)[0]
+        ref, ref_h, _ = wan_dit.dit_forward(sd, cfg, [x], t, ctx, Lt, return_hidden=True)
+        tru, tru_h, _ = _truth_forward(sd, cfg, [x], t, ctx, Lt, return_hidden=True)
+    assert len(hidden) == 4
+    for depth in (1, 2, 4):
+        assert_model_close(hidden[depth - 1], ref_h[depth - 1][0], tru_h[depth - 1][0], frac=FULL_LENGTH_GATE[depth][0],
+                           max_rel=FULL_LENGTH_GATE[depth][1], truth_ratio=1.02, name=f"TI2V-5B width, residual stream after block {depth} (L=11440, CPU oracle)")
+    assert_model_close(out, ref[0], tru[0], frac=FULL_LENGTH_GATE["out"][0], max_rel=FULL_LENGTH_GATE["out"][1], truth_ratio=1.02,
+                       name="TI2V-5B width, 4-block forward output (L=11440, CPU oracle)")
+
+
 def _trained_regime_state_dict(sd, cfg, outliers=(5, 777, 1500, 3001)):
     """Pushes deterministic-init weights into the numeric regime of a TRAINED Wan checkpoint (the statistics the detinit / random-context
     parity runs do not exercise): a few residual-stream channels hundreds of times larger than the rest (outlier channels), attention
