@@ -619,7 +619,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0w + r;
-    if (q < p.Lq) {
+    if ((p.ldo & 7) == 0) {
+        // O through LDS: in the MFMA's layout a lane owns 16 pieces of 8 bytes along its query's row, and stored directly every
+        // store instruction touches 32 rows with 16 bytes each (3.4 us of store issue per workgroup, tools/diag/attn_timeline;
+        // cross-attention at the DiT shape 218 -> 208 us in a same-device A/B, bit-identical).
+        // Each wave transposes through its own 32 x 272-byte image (the K / V^T buffers are free: the last tile ended on a barrier)
+        // and stores 4 whole 256-byte row segments per instruction.
+        constexpr int RS = 272;
+        char* const img = smem + wave_u * (32 * RS);
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 o = {pack16_2<false>(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv),
+                           pack16_2<false>(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv)};
+                *(u32x2*)(img + r * RS + 64 * d + 16 * g + 8 * h) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private image: no barrier
+        const int srow = lane >> 4, chunk = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + srow;
+            const u32x4 v = *(const u32x4*)(img + row * RS + chunk * 16);
+            if (q0w + row < p.Lq) *(u32x4*)(p.out + (long)(q0w + row) * p.ldo + hcol + chunk * 8) = v;
+        }
+    } else if (q < p.Lq) {
         bf16_t* op = p.out + (long)q * p.ldo + hcol + 4 * h;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
@@ -911,7 +935,37 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0w + r;
-    if (q < p.Lq) {
+    if ((p.ldo & 7) == 0) {
+        // O through LDS (as in flash_attn_fwd3_kernel), in two passes of two d-blocks each: twelve wave-private images of 32 rows x
+        // (128 + 16) bytes fit the 64 KiB that held K / V^T (free: the last tile ended on a barrier that the loader-only waves took too);
+        // every store instruction writes 8 whole 128-byte lines (self-attention at the DiT shape 2.724 -> 2.711 ms in a same-device A/B,
+        // bit-identical).
+        constexpr int RS = 144;
+        char* const img = smem + wave_u * (32 * RS);
+        const int srow = lane >> 3, chunk = lane & 7;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 2 * half + dd;
+                    u32x2 o = {pack16_2<false>(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv),
+                               pack16_2<false>(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv)};
+                    *(u32x2*)(img + r * RS + 64 * dd + 16 * g + 8 * h) = o;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private image: no barrier
+            u32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *(const u32x4*)(img + (8 * i + srow) * RS + chunk * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the second pass overwrites the image
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + srow;
+                if (q0w + row < p.Lq) *(u32x4*)(p.out + (long)(q0w + row) * p.ldo + hcol + 64 * half + chunk * 8) = v[i];
+            }
+        }
+    } else if (q < p.Lq) {
         bf16_t* op = p.out + (long)q * p.ldo + hcol + 4 * h;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
