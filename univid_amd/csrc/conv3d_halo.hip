@@ -22,17 +22,21 @@
 
 typedef __attribute__((address_space(3))) void lds_void_h;
 
-template <int PREC>
-__global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
+// TW = 32: 8 waves on an 8 x 32 patch, one workgroup per CU (the bf16x6 form). TW = 16: 4 waves on an 8 x 16 patch, 55 KiB of LDS, TWO
+// independent workgroups per CU that cover each other's barrier stalls (what the exact-f32 arithmetic, bound by its MFMA, needs).
+template <int PREC, int TW = 32>
+__global__ __launch_bounds__(TW * 16) void conv3d_halo_kernel(ConvArgs p) {
     static_assert(PREC == 0 || PREC == 3, "exact-f32 MFMA or f32-grade bf16x6");
-    constexpr int TH = 8, TW = 32, HW_ = TW + 2, NHP = (TH + 2) * HW_;        // 340 halo pixels
-    constexpr int BN = 128, NW = 8, TM = 4, TN = 4;
+    static_assert(TW == 32 || TW == 16, "patch width");
+    constexpr int TH = 8, HW_ = TW + 2, NHP = (TH + 2) * HW_;                   // 340 / 180 halo pixels
+    constexpr int BN = 128, NW = TW / 4, NT = NW * 64, TM = 4, TN = 4;
     constexpr int HALO_ROW = PREC == 3 ? 64 : 128;                              // bytes per halo pixel (per plane for PREC 3)
-    constexpr int HALO_PLANE = 344 * HALO_ROW;                                  // 340 pixels padded to whole 8-pixel groups
+    constexpr int NHP8 = (NHP + 7) / 8 * 8;                                      // padded to whole 8-pixel groups
+    constexpr int HALO_PLANE = NHP8 * HALO_ROW;
     constexpr int HALO_BYTES = (PREC == 3 ? 3 : 1) * HALO_PLANE;
     constexpr int W_BYTES = PREC == 3 ? BN * 192 : BN * 128;
     constexpr int W_PIECES = W_BYTES / 1024, W_INSTR = W_PIECES / NW;            // 16 / 24 pieces -> 2 / 3 per wave
-    constexpr int NLD = 6;                                                      // 340 x 8 sixteen-byte chunks over 512 lanes
+    constexpr int NLD = (NHP * 8 + NT - 1) / NT;                                // sixteen-byte chunks of the halo per lane (6)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wbuf = smem + HALO_BYTES;
 
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
     unsigned h_lds[NLD];         // LDS byte offset the chunk (its first plane) is written to
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
-        const int s = it * 512 + tid, hp = s >> 3, ch = s & 7;
+        const int s = it * NT + tid, hp = s >> 3, ch = s & 7;
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int y = ty0 + hy - 1, x = tx0 + hx - 1;                          // coordinates of the convolution's input image
         const bool ok = hp < NHP && (unsigned)y < (unsigned)p.Hout && (unsigned)x < (unsigned)p.Wout;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
         h_off[it] = ok ? ((long)sy * p.Win + sx) * p.ld_in + ch * 4 : 0;
         if constexpr (PREC == 3) h_lds[it] = hp * 64 + ((((ch >> 1) ^ ((0x1320 >> (4 * ((hp >> 2) & 3))) & 3)) << 4) | ((ch & 1) << 3));
         else h_lds[it] = hp * 128 + ((ch ^ ((hp >> 1) & 7)) << 4);
-        if (hp >= 344) h_lds[it] = 0xffffffffu;                                // beyond the padded image: never written
+        if (hp >= NHP8) h_lds[it] = 0xffffffffu;                               // beyond the padded image: never written
     }
     f32x4 hreg[NLD];
     // group g = (dt, channel block cb): dt = g / ncb, cb = g % ncb
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
     const int frow = lane & 15, fq = lane >> 4;
     int hpb[TM];                 // halo pixel of this lane's output pixel of fragment j for tap (0, 0)
 #pragma unroll
-    for (int j = 0; j < TM; ++j) hpb[j] = (wm * 2 + (j >> 1)) * HW_ + (j & 1) * 16 + frow;
+    for (int j = 0; j < TM; ++j) hpb[j] = TW == 32 ? (wm * 2 + (j >> 1)) * HW_ + (j & 1) * 16 + frow : (wm * 4 + j) * HW_ + frow;
     int w_off[TN], w_key[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
     // ---- epilogue: bias, optional residual, f32 store (pixel m = (frame, y, x) of the output tensor)
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int py = wm * 2 + (j >> 1), px = (j & 1) * 16 + frow;
+        const int py = TW == 32 ? wm * 2 + (j >> 1) : wm * 4 + j, px = TW == 32 ? (j & 1) * 16 + frow : frow;
         const int y = ty0 + py, x = tx0 + px;
         if (y >= p.Hout || x >= p.Wout) continue;
         const long m = ((long)tf * p.Hout + y) * p.Wout + x;
@@ -265,37 +269,37 @@ __global__ __launch_bounds__(512) void conv3d_halo_kernel(ConvArgs p) {
 // Which convolutions take the halo kernel: 3x3 spatial taps, stride 1, padding 1 (plain or behind the 2x upsampling), no interleave, whole 32-channel input
 // blocks (all callers pad), whole 128-wide output-channel tiles, and enough tiles per frame to fill the chip at four frames per pass.
 // UV_CONV_HALO in the environment (developer A/B knob and test hook, read per call): "0" = never, "1" = whenever the geometry fits
-// (also launches too small to fill the chip, which the tests use), unset = automatic.
+// (also launches too small to fill the chip, which the tests use), unset = automatic (both arithmetics).
 bool uv_conv3d_halo_eligible(const ConvArgs& a, int prec) {
     const char* e = getenv("UV_CONV_HALO");
     if (e && e[0] == '0') return false;
     if (!(prec == 0 || prec == 3)) return false;
-    // exact f32 runs on the halo kernel only when asked to (tests; A/B): its MFMA is 16x slower than the bf16 one, the gather kernel is
-    // already matrix-pipe-bound there (83 % of the f32 MFMA peak), and two independent 4-wave workgroups per CU hide its barrier stalls
-    // better than this kernel's one 8-wave workgroup: measured 6.49 s (halo) against 6.40 s (gather) per 49 x 720 x 1280 decode.
-    if (prec == 0 && !(e && e[0] == '1')) return false;
     if (a.kh != 3 || a.kw != 3 || (a.kt != 3 && a.kt != 1)) return false;
     if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.interleave) return false;
     const int mul = a.up ? 2 : 1;                            // up: the halo image is filled through the 2x nearest-exact map
     if (a.Hin * mul != a.Hout || a.Win * mul != a.Wout || a.Cout % 128 != 0 || a.Cin % 32 != 0) return false;
     // per-FRAME tile count: the choice must not depend on how many frames a pass carries (the pass length is a memory / speed knob
     // that leaves results bit-identical, and the two kernels sum their k-tiles in different orders)
-    const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * (a.Cout / 128);
-    return (e && e[0] == '1') || 4 * tiles >= uv_num_cus();
+    // (exact f32: 8 x 16 patches on 4-wave workgroups, two per CU - 6.28 s against 6.43 s per 49 x 720 x 1280 decode on the gather kernel,
+    // same process, interleaved; the 8-wave form of round 3's first version lost to it, 6.49 s, with one workgroup per CU)
+    const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + (prec == 3 ? 31 : 15)) / (prec == 3 ? 32 : 16)) * (a.Cout / 128);
+    return (e && e[0] == '1') || 4 * tiles >= (prec == 3 ? 1 : 2) * uv_num_cus();
 }
 
 int uv_launch_conv3d_halo(ConvArgs& a, int prec, hipStream_t stream) {
     a.tiles_n = a.Cout / 128;
-    a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
-    const size_t lds = prec == 3 ? 3 * 344 * 64 + 2 * 128 * 192 : 344 * 128 + 2 * 128 * 128;
     static bool attr_set[UV_MAX_DEV][2];
     bool& attr = attr_set[uv_cur_dev()][prec == 3];
     if (prec == 3) {
-        if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(conv3d_halo_kernel<3>, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+        a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
+        const size_t lds = 3 * 344 * 64 + 2 * 128 * 192;
+        if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv3d_halo_kernel<3, 32>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
     } else {
-        if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(conv3d_halo_kernel<0>, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+        a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 15) / 16);
+        const size_t lds = 184 * 128 + 2 * 128 * 128;          // 55 KiB: two workgroups per CU
+        if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv3d_halo_kernel<0, 16>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
     }
     attr = true;
     return 0;
