@@ -10,48 +10,67 @@
 // y = x / max(||x||_2, 1e-12) * sqrt(C) * gamma  [-> SiLU]      (F.normalize(x, dim=C) * scale * gamma)
 // split_out: write each value as bf16 hi + bf16 lo in the [C/32][32 hi | 32 lo] layout uv_conv3d_bf16x3(in_split=1) reads
 // (same bytes per pixel as f32).
-template <int MAXV>
+// One wave per RPW consecutive rows (pixels): the loads of all RPW rows are issued before the first reduction, so a wave keeps RPW rows
+// in flight - at C = 160 a row is 640 bytes, and one row per wave left the kernel latency-bound at 2.9 TB/s (32 waves x 640 B per CU).
+// MAXV = ceil(C / 256) exactly (chosen by the launcher): every load is issued unconditionally from a clamped column (lanes beyond the
+// row re-read its last chunk and contribute zero) - guarded loads compile to one basic block and one vmcnt(0) EACH (the C = 1024
+// rows of the decoder's first stage ran at 2.3 TB/s behind eight guarded loads).
+template <int MAXV, int RPW>
 __global__ __launch_bounds__(256) void vae_rms_silu_kernel(const float* in, long ld_in, const float* gamma, float* out,
                                                           long ld_out, long P, int C, int do_silu, int split_out) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= P) return;
-    const float* xr = in + row * ld_in;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= P) return;
     const int nv = C >> 2;  // float4 count
-    f32x4 v[MAXV];
-    float ss = 0.f;
+    f32x4 v[RPW][MAXV];
+    float ss[RPW];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c4 = i * 64 + lane;
-        if (c4 < nv) {
-            v[i] = *(const f32x4*)(xr + c4 * 4);
-            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-        }
+    for (int r = 0; r < RPW; ++r) {
+        const float* xr = in + min(row0 + r, P - 1) * ld_in;      // rows beyond P: a valid row re-read, never stored
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) v[r][i] = *(const f32x4*)(xr + min(i * 64 + lane, nv - 1) * 4);
     }
-    const float denom = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    f32x4 g[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) g[i] = *(const f32x4*)(gamma + min(i * 64 + lane, nv - 1) * 4);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const float q = v[r][i][0] * v[r][i][0] + v[r][i][1] * v[r][i][1] + v[r][i][2] * v[r][i][2] + v[r][i][3] * v[r][i][3];
+            a += (i * 64 + lane < nv) ? q : 0.f;
+        }
+        ss[r] = a;
+    }
     const float scale = sqrtf((float)C);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c4 = i * 64 + lane;
-        if (c4 < nv) {
-            const f32x4 g = *(const f32x4*)(gamma + c4 * 4);
+    for (int r = 0; r < RPW; ++r) {
+        const long row = row0 + r;
+        const float denom = fmaxf(sqrtf(wave_sum(ss[r])), 1e-12f);
+        if (row >= P) continue;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = i * 64 + lane;
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float t = __fmul_rn(__fmul_rn(__fdiv_rn(v[i][e], denom), scale), g[e]);
+                float t = __fmul_rn(__fmul_rn(__fdiv_rn(v[r][i][e], denom), scale), g[i][e]);
                 if (do_silu) t = silu_f32(t);
                 y[e] = t;
             }
-            if (split_out) {
-                const int c = c4 * 4;
-                bf16_t* ob = (bf16_t*)(out + row * ld_out) + (c >> 5) * 64 + (c & 31);
-                float lo[4];
+            if (c4 < nv) {
+                if (split_out) {
+                    const int c = c4 * 4;
+                    bf16_t* ob = (bf16_t*)(out + row * ld_out) + (c >> 5) * 64 + (c & 31);
+                    float lo[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) lo[e] = y[e] - round_bf(y[e]);
-                *(u32x2*)ob = (u32x2){pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-                *(u32x2*)(ob + 32) = (u32x2){pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3])};
-            } else {
-                *(f32x4*)(out + row * ld_out + c4 * 4) = y;
+                    for (int e = 0; e < 4; ++e) lo[e] = y[e] - round_bf(y[e]);
+                    *(u32x2*)ob = (u32x2){pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+                    *(u32x2*)(ob + 32) = (u32x2){pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3])};
+                } else {
+                    *(f32x4*)(out + row * ld_out + c4 * 4) = y;
+                }
             }
         }
     }
@@ -62,9 +81,19 @@ extern "C" int uv_vae_rms_silu(const float* in, long ld_in, const float* gamma, 
     UV_CHECK_ARG(in && gamma && out && P > 0, "uv_vae_rms_silu: bad arguments");
     UV_CHECK_ARG(!split_out || C % 32 == 0, "uv_vae_rms_silu: split output needs C %% 32 == 0 (C=%d)", C);
     UV_CHECK_ARG(C % 4 == 0 && C <= 2048 && ld_in % 4 == 0 && ld_out % 4 == 0, "uv_vae_rms_silu: C=%d unsupported", C);
-    const dim3 grid((unsigned)((P + 3) / 4)), block(256);
-    if (C <= 512) hipLaunchKernelGGL(vae_rms_silu_kernel<2>, grid, block, 0, (hipStream_t)stream, in, ld_in, gamma, out, ld_out, P, C, do_silu, split_out);
-    else hipLaunchKernelGGL(vae_rms_silu_kernel<8>, grid, block, 0, (hipStream_t)stream, in, ld_in, gamma, out, ld_out, P, C, do_silu, split_out);
+    const dim3 block(256);
+    const int maxv = (C + 255) / 256;                    // float4 chunks per lane
+#define UV_RMS_LAUNCH(MV, RPW)                                                                                                          \
+    hipLaunchKernelGGL((vae_rms_silu_kernel<MV, RPW>), dim3((unsigned)((P + 4 * RPW - 1) / (4 * RPW))), block, 0, (hipStream_t)stream, in, \
+                       ld_in, gamma, out, ld_out, P, C, do_silu, split_out)
+    switch (maxv) {
+        case 1: UV_RMS_LAUNCH(1, 4); break;              // rows of at most 1 KiB: four per wave
+        case 2: UV_RMS_LAUNCH(2, 2); break;
+        case 3: UV_RMS_LAUNCH(3, 1); break;
+        case 4: UV_RMS_LAUNCH(4, 1); break;
+        default: UV_RMS_LAUNCH(8, 1); break;
+    }
+#undef UV_RMS_LAUNCH
     UV_CHECK_LAUNCH("uv_vae_rms_silu");
     return 0;
 }
