@@ -40,15 +40,21 @@ def L():
     return _lib
 
 
-def assert_bf16_kernel(got, ref, max_ulp=1.0, min_exact=0.999, name="", extra=None):
+def assert_bf16_kernel(got, ref, max_ulp=1.0, min_exact=0.999, name="", extra=None, rare=None):
     """Every element within `max_ulp` bf16 ulps of the oracle (+ an absolute floor of 2e-5 * max|ref| for results that
     are small only through cancellation, where fp32 accumulation-order noise is many ulps OF THE RESULT), and at least
-    `min_exact` of the elements bit-identical."""
+    `min_exact` of the elements bit-identical. rare = (fraction, slack): at most `fraction` of the elements may exceed that
+    bound, by at most `slack` (a tensor or a number) - for kernels with an INTERMEDIATE bf16 rounding point, where an fp32
+    summation-order difference flips that rounding on about one element per million."""
     got, ref = got.float().cpu(), ref.float().cpu()
     assert torch.isfinite(got).all(), name
     d = (got - ref).abs()
     ulp = bf16_ulp(torch.maximum(ref.abs(), got.abs()))
     tol = max_ulp * ulp + 2e-5 * ref.abs().max() + (0 if extra is None else extra)
+    if rare is not None:
+        over = d > tol
+        assert over.float().mean().item() <= rare[0], f"{name}: {int(over.sum())} of {d.numel()} elements beyond {max_ulp} ulp"
+        tol = tol + rare[1]
     assert (d <= tol).all(), f"{name}: max excess {float((d - tol).max()):.3e} (max err {float(d.max()):.3e})"
     exact = (d == 0).float().mean().item()
     assert exact >= min_exact, f"{name}: only {exact:.5f} bit-identical"
@@ -423,7 +429,7 @@ def test_full_size_glue_kernels_sampled_rows_vs_oracle():
     M = B * Ls
     g = torch.Generator(device=DEV).manual_seed(17)
     rows = torch.unique(torch.cat([torch.tensor([0, 1, 3, 4, 255, 256, 879, 880, Ls - 1, Ls, Ls + 1, Ls + 879, Ls + 880, M - 2, M - 1]),
-                                   torch.randint(0, M, (48,))]))
+                                   torch.randint(0, M, (48,), generator=torch.Generator().manual_seed(170))]))
     x = torch.randn(M, C, device=DEV, generator=g) * 2 + 0.3
     tab = torch.randn(2, 6 * C, device=DEV, generator=g) * 0.3
     tid = (torch.arange(M, device=DEV) % Ls >= 880).to(torch.int32)          # i2v-like: first latent frame on its own row
@@ -456,7 +462,12 @@ def test_full_size_glue_kernels_sampled_rows_vs_oracle():
             xi = torch.view_as_complex(y[i].to(torch.float64).reshape(H, -1, 2))
             out_rows.append(torch.view_as_real(xi * fi).flatten(1).float())
         ref = torch.stack(out_rows).reshape(len(pos), C).to(BF16)
-        assert_bf16_kernel(got, ref, name=f"full-size rmsnorm+rope {nm}")
+        # WanRMSNorm rounds the normalised value to bf16 BEFORE the weight and the rotation (model.py:79-96); kernel and oracle sum the
+        # row's squares in different fp32 orders, which flips that rounding on about one element per million
+        # (tests/manual/rope_ulp_stats.py: 23 of 22.4 M), and the rotation spreads the flip - one ulp of the larger element of the
+        # rotated pair - over both outputs. Allowed: that much, on at most 2e-5 of the elements.
+        ypair = y.reshape(len(pos), C // 2, 2).abs().amax(dim=2, keepdim=True).expand(-1, -1, 2).reshape(len(pos), C)
+        assert_bf16_kernel(got, ref, name=f"full-size rmsnorm+rope {nm}", rare=(2e-5, 2.0 * bf16_ulp(ypair)))
     # gated fp32 residual epilogue (x + bf16(acc + bias) * gate[tid]) of the o-projection shape
     a = (torch.rand(M, C, device=DEV, generator=g) * 2 - 1).to(BF16)
     wo = ((torch.rand(C, C, device=DEV, generator=g) * 2 - 1) * 0.05).to(BF16)
