@@ -24,12 +24,14 @@ typedef __attribute__((address_space(3))) void lds_void_h;
 
 // TW = 32: 8 waves on an 8 x 32 patch, one workgroup per CU (the bf16x6 form). TW = 16: 4 waves on an 8 x 16 patch, 55 KiB of LDS, TWO
 // independent workgroups per CU that cover each other's barrier stalls (what the exact-f32 arithmetic, bound by its MFMA, needs).
-template <int PREC, int TW = 32>
-__global__ __launch_bounds__(TW * 16) void conv3d_halo_kernel(ConvArgs p) {
+// BN = output channels per workgroup: 128, or 160 for the encoder's 160 / 320-channel stages (exact f32 only).
+template <int PREC, int TW = 32, int BN = 128>
+__global__ __launch_bounds__(TW * 16) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3d_halo_kernel(ConvArgs p) {   // 2 waves per SIMD in every form: <= 256 registers
     static_assert(PREC == 0 || PREC == 3, "exact-f32 MFMA or f32-grade bf16x6");
     static_assert(TW == 32 || TW == 16, "patch width");
     constexpr int TH = 8, HW_ = TW + 2, NHP = (TH + 2) * HW_;                   // 340 / 180 halo pixels
-    constexpr int BN = 128, NW = TW / 4, NT = NW * 64, TM = 4, TN = 4;
+    static_assert(BN == 128 || (BN == 160 && PREC == 0 && TW == 16), "output-channel tile");
+    constexpr int NW = TW / 4, NT = NW * 64, TM = 4, TN = BN / 32;
     constexpr int HALO_ROW = PREC == 3 ? 64 : 128;                              // bytes per halo pixel (per plane for PREC 3)
     constexpr int NHP8 = (NHP + 7) / 8 * 8;                                      // padded to whole 8-pixel groups
     constexpr int HALO_PLANE = NHP8 * HALO_ROW;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(TW * 16) void conv3d_halo_kernel(ConvArgs p) {
     int w_off[TN], w_key[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-        const int row = wn * 64 + i * 16 + frow;
+        const int row = wn * (BN / 2) + i * 16 + frow;
         if constexpr (PREC == 3) {
             w_off[i] = row * 64 + ((fq ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3)) << 4);
             w_key[i] = 0;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(TW * 16) void conv3d_halo_kernel(ConvArgs p) {
         const long m = ((long)tf * p.Hout + y) * p.Wout + x;
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + 4 * fq;
+            const int n = n0 + wn * (BN / 2) + i * 16 + 4 * fq;
             if (n >= p.Cout) continue;
             f32x4 v = acc[i][j];
             if (p.bias) {
@@ -270,6 +272,13 @@ __global__ __launch_bounds__(TW * 16) void conv3d_halo_kernel(ConvArgs p) {
 // blocks (all callers pad), whole 128-wide output-channel tiles, and enough tiles per frame to fill the chip at four frames per pass.
 // UV_CONV_HALO in the environment (developer A/B knob and test hook, read per call): "0" = never, "1" = whenever the geometry fits
 // (also launches too small to fill the chip, which the tests use), unset = automatic (both arithmetics).
+// output-channel tile of the halo kernel for this convolution (0: none fits): whole 128-wide tiles, or - exact f32 - whole 160-wide ones
+static int uv_conv3d_halo_bn(const ConvArgs& a, int prec) {
+    if (a.Cout % 128 == 0) return 128;
+    if (prec == 0 && a.Cout % 160 == 0) return 160;
+    return 0;
+}
+
 bool uv_conv3d_halo_eligible(const ConvArgs& a, int prec) {
     const char* e = getenv("UV_CONV_HALO");
     if (e && e[0] == '0') return false;
@@ -277,24 +286,31 @@ bool uv_conv3d_halo_eligible(const ConvArgs& a, int prec) {
     if (a.kh != 3 || a.kw != 3 || (a.kt != 3 && a.kt != 1)) return false;
     if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.interleave) return false;
     const int mul = a.up ? 2 : 1;                            // up: the halo image is filled through the 2x nearest-exact map
-    if (a.Hin * mul != a.Hout || a.Win * mul != a.Wout || a.Cout % 128 != 0 || a.Cin % 32 != 0) return false;
+    const int bn = uv_conv3d_halo_bn(a, prec);
+    if (a.Hin * mul != a.Hout || a.Win * mul != a.Wout || bn == 0 || a.Cin % 32 != 0) return false;
     // per-FRAME tile count: the choice must not depend on how many frames a pass carries (the pass length is a memory / speed knob
     // that leaves results bit-identical, and the two kernels sum their k-tiles in different orders)
     // (exact f32: 8 x 16 patches on 4-wave workgroups, two per CU - 6.28 s against 6.43 s per 49 x 720 x 1280 decode on the gather kernel,
     // same process, interleaved; the 8-wave form of round 3's first version lost to it, 6.49 s, with one workgroup per CU)
-    const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + (prec == 3 ? 31 : 15)) / (prec == 3 ? 32 : 16)) * (a.Cout / 128);
+    const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + (prec == 3 ? 31 : 15)) / (prec == 3 ? 32 : 16)) * (a.Cout / bn);
     return (e && e[0] == '1') || 4 * tiles >= (prec == 3 ? 1 : 2) * uv_num_cus();
 }
 
 int uv_launch_conv3d_halo(ConvArgs& a, int prec, hipStream_t stream) {
-    a.tiles_n = a.Cout / 128;
-    static bool attr_set[UV_MAX_DEV][2];
-    bool& attr = attr_set[uv_cur_dev()][prec == 3];
+    const int bn = uv_conv3d_halo_bn(a, prec);
+    a.tiles_n = a.Cout / bn;
+    static bool attr_set[UV_MAX_DEV][3];
+    bool& attr = attr_set[uv_cur_dev()][prec == 3 ? 1 : bn == 160 ? 2 : 0];
     if (prec == 3) {
         a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
         const size_t lds = 3 * 344 * 64 + 2 * 128 * 192;
         if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((conv3d_halo_kernel<3, 32>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+    } else if (bn == 160) {
+        a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 15) / 16);
+        const size_t lds = 184 * 128 + 2 * 160 * 128;          // 63 KiB: two workgroups per CU
+        if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<0, 16, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv3d_halo_kernel<0, 16, 160>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
     } else {
         a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 15) / 16);
         const size_t lds = 184 * 128 + 2 * 128 * 128;          // 55 KiB: two workgroups per CU
