@@ -25,8 +25,10 @@ typedef __attribute__((address_space(3))) void lds_void_h;
 // TW = 32: 8 waves on an 8 x 32 patch, one workgroup per CU (the bf16x6 form). TW = 16: 4 waves on an 8 x 16 patch, 55 KiB of LDS, TWO
 // independent workgroups per CU that cover each other's barrier stalls (what the exact-f32 arithmetic, bound by its MFMA, needs).
 // BN = output channels per workgroup: 128, or 160 for the encoder's 160 / 320-channel stages (exact f32 only).
-template <int PREC, int TW = 32, int BN = 128>
-__global__ __launch_bounds__(TW * 16) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3d_halo_kernel(ConvArgs p) {   // 2 waves per SIMD in every form: <= 256 registers
+// WBUF = weight buffers: 2 (next tap's weights land while this tap computes), or 1 - 39 KiB of LDS and <= 168 registers, THREE
+// workgroups per CU that cover each other's weight waits (exact f32, 128-wide tile).
+template <int PREC, int TW = 32, int BN = 128, int WBUF = 2>
+__global__ __launch_bounds__(TW * 16) __attribute__((amdgpu_waves_per_eu(WBUF == 1 ? 3 : 2, WBUF == 1 ? 3 : 2))) void conv3d_halo_kernel(ConvArgs p) {
     static_assert(PREC == 0 || PREC == 3, "exact-f32 MFMA or f32-grade bf16x6");
     static_assert(TW == 32 || TW == 16, "patch width");
     constexpr int TH = 8, HW_ = TW + 2, NHP = (TH + 2) * HW_;                   // 340 / 180 halo pixels
@@ -222,6 +224,21 @@ __global__ __launch_bounds__(TW * 16) __attribute__((amdgpu_waves_per_eu(2, 2)))
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
+    if constexpr (WBUF == 1) {
+        for (int g = 0; g < ngroups; ++g) {
+            const bool more = g + 1 < ngroups;
+            if (more) load_halo(g + 1);
+            for (int tap = 0; tap < 9; ++tap) {
+                compute(tap, wbuf, smem);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __syncthreads();                              // every wave has read this tap's weights (and, at tap 8, the halo)
+                if (tap < 8) UV_HALO_STAGE_W(g, tap + 1, 0);
+                else if (more) { UV_HALO_STAGE_W(g + 1, 0, 0); write_halo(smem); }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    } else
     for (int g = 0; g < ngroups; ++g) {
         const bool more = g + 1 < ngroups;
         if (more) load_halo(g + 1);
@@ -313,9 +330,10 @@ int uv_launch_conv3d_halo(ConvArgs& a, int prec, hipStream_t stream) {
         hipLaunchKernelGGL((conv3d_halo_kernel<0, 16, 160>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
     } else {
         a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 15) / 16);
-        const size_t lds = 184 * 128 + 2 * 128 * 128;          // 55 KiB: two workgroups per CU
-        if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv3d_halo_kernel<0, 16>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
+        // single weight buffer: 39 KiB of LDS and 168 registers, three workgroups per CU (6.19-6.21 s against 6.26 s per decode with two
+        // double-buffered workgroups per CU, same process, interleaved, bit-identical: the k order is the same)
+        const size_t lds = 184 * 128 + 128 * 128;
+        hipLaunchKernelGGL((conv3d_halo_kernel<0, 16, 128, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
     }
     attr = true;
     return 0;
