@@ -129,18 +129,30 @@ extern "C" int uv_softmax_rows_f32(float* x, long ld, int R, int n, float scale,
 // DupUp3D (vae2_2.py:390-412) added onto the main path: out[t',h',w',co] += x[t'/ft, h'/2, w'/2, j / repeats],
 // j = ((co*ft + t'%ft)*2 + h'%2)*2 + w'%2, repeats = Cout*ft*4 / Cin; `drop` leading frames are skipped
 // (first_chunk: ft-1).  x: [T, H, W, Cin]; out: [T*ft - drop, 2H, 2W, Cout].
+// One thread per 4 consecutive output channels (Cout % 4 == 0: a 16-byte read-modify-write of `out`; the four source channels are
+// j / repeats for four different j, gathered from a row that stays in cache) - or per channel (VEC = 1).
+template <int VEC>
 __global__ void dupup_add_kernel(const float* x, float* out, int T, int H, int W, int Cin, int Cout, int ft, int drop) {
     const int To = T * ft - drop, Ho = 2 * H, Wo = 2 * W;
-    const long total = (long)To * Ho * Wo * Cout;
+    const int cv = Cout / VEC;
+    const long total = (long)To * Ho * Wo * cv;
     const int repeats = Cout * ft * 4 / Cin;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Cout);
-        long r = i / Cout;
+        const int co = (int)(i % cv) * VEC;
+        long r = i / cv;
         const int wo = (int)(r % Wo); r /= Wo;
         const int ho = (int)(r % Ho);
         const int to = (int)(r / Ho) + drop;
-        const int j = ((co * ft + to % ft) * 2 + (ho & 1)) * 2 + (wo & 1);
-        out[i] += x[(((long)(to / ft) * H + (ho >> 1)) * W + (wo >> 1)) * Cin + j / repeats];
+        const float* xr = x + (((long)(to / ft) * H + (ho >> 1)) * W + (wo >> 1)) * Cin;
+        const int sub = (to % ft) * 4 + (ho & 1) * 2 + (wo & 1);          // j = co * ft * 4 + sub
+        if constexpr (VEC == 4) {
+            f32x4 o = *(f32x4*)(out + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += xr[((co + e) * ft * 4 + sub) / repeats];
+            *(f32x4*)(out + i * 4) = o;
+        } else {
+            out[i] += xr[(co * ft * 4 + sub) / repeats];
+        }
     }
 }
 
@@ -148,8 +160,12 @@ extern "C" int uv_vae_dupup_add(const float* x, float* out, int T, int H, int W,
                                 void* stream) {
     UV_CHECK_ARG(x && out && (Cout * ft * 4) % Cin == 0, "uv_vae_dupup_add: bad arguments");
     const long total = (long)(T * ft - drop) * 2 * H * 2 * W * Cout;
-    hipLaunchKernelGGL(dupup_add_kernel, dim3((unsigned)min((total + 255) / 256, (long)8192)), dim3(256), 0,
-                       (hipStream_t)stream, x, out, T, H, W, Cin, Cout, ft, drop);
+    if (Cout % 4 == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(dupup_add_kernel<4>, dim3((unsigned)min((total / 4 + 255) / 256, (long)16384)), dim3(256), 0,
+                           (hipStream_t)stream, x, out, T, H, W, Cin, Cout, ft, drop);
+    else
+        hipLaunchKernelGGL(dupup_add_kernel<1>, dim3((unsigned)min((total + 255) / 256, (long)8192)), dim3(256), 0,
+                           (hipStream_t)stream, x, out, T, H, W, Cin, Cout, ft, drop);
     UV_CHECK_LAUNCH("uv_vae_dupup_add");
     return 0;
 }
