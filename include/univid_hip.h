@@ -28,6 +28,20 @@ int uv_init(void);                         /* one-time allocations for the CURRE
 const char* uv_last_error(void);           /* thread-local text of the last failure */
 int uv_device_arch(char* buf, int len);    /* e.g. "gfx950:sramecc+:xnack-" */
 
+/* Developer options: process-wide switches for A/B tools and tests, set EXPLICITLY through these calls - the library never reads the
+ * environment. Defaults are what production runs; none of them changes results beyond the f32 summation order noted per key.
+ *   UV_OPT_CONV_HALO  -1 automatic (default) | 0 never | 1 whenever the geometry fits: which 3x3 stride-1 convolutions of uv_conv3d_* take
+ *                     the LDS-halo kernel instead of the gather kernel (the two sum their k-tiles in different orders: ~1e-5 apart)
+ *   UV_OPT_GEMM_GM    0 automatic (default) | 1..64: tile-walk group height of the persistent GEMM (tile order only, results unchanged)
+ *   UV_OPT_ATTN_CUT   0 automatic (default) | v: flash_attn_fwd12_kernel cuts every head with v - 1 eight-unit blocks (results unchanged)
+ * uv_set_option rejects unknown keys / out-of-range values; uv_reset_options restores every default. Host-only, thread-safe. */
+#define UV_OPT_CONV_HALO 0
+#define UV_OPT_GEMM_GM 1
+#define UV_OPT_ATTN_CUT 2
+int uv_set_option(int key, int value);
+int uv_get_option(int key, int* value);
+int uv_reset_options(void);
+
 /* ---- DiT: GEMMs -------------------------------------------------------------------------------------------- */
 /* epilogue selectors of uv_gemm_bf16_nt */
 #define UV_EPI_BF16 0            /* out_bf16 = bf16(acc + bias)                               nn.Linear under autocast */

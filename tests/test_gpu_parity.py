@@ -35,6 +35,15 @@ def _init():
     yield
 
 
+@pytest.fixture(autouse=True)
+def _default_options():
+    """Developer switches (uv_set_option) are process-wide: every test starts from and leaves the production defaults."""
+    from univid_amd import _lib
+    _lib.reset_options()
+    yield
+    _lib.reset_options()
+
+
 def L():
     from univid_amd import _lib
     return _lib
@@ -81,10 +90,12 @@ def assert_f32_close(got, ref, rtol=1e-3, atol=1e-4, name=""):
     assert bad == 0, f"{name}: {bad}/{ref.numel()} outside rtol={rtol} atol={atol}; max abs {float((got - ref).abs().max()):.3e}"
 
 
-def assert_model_close(got, ref, truth=None, frac=0.93, name="", max_rel=6e-4, truth_ratio=1.02):
+def assert_model_close(got, ref, truth=None, frac=0.946, name="", max_rel=4.6e-4, truth_ratio=1.02):
     """Composite-path gate: fraction of elements inside rtol 1e-3 / atol 1e-4, max |err| / range, and rms error against the
-    no-rounding truth run relative to the oracle's own. Every gate is what MI355X measured (profiles/r02_parity_margins.json)
-    x 1.5 - for a fraction: 1.5 x the measured OUTSIDE fraction. The defaults are the tiny-DiT forwards (measured 95.6-96.1 %
+    no-rounding truth run relative to the oracle's own. Every gate is what MI355X measured over rounds 2 and 3
+    (profiles/r02_parity_margins.json, r03_parity_margins.json: the two agree to the fourth digit on the fractions) x 1.2 - for the
+    maximum error: 1.2 x the larger of the two rounds; for a fraction: the tighter of 1 - 1.2 x the measured OUTSIDE fraction and the
+    measured inside fraction / 1.2 (round 4; x 1.5 before). The defaults are the tiny-DiT forwards (measured 95.6-96.1 %
     inside, max 3.8e-4 of the range, truth ratio 0.999-1.001); wider models pass their own numbers. The measured values are
     written to the margins file again on every run (conftest.record_margin)."""
     got, ref = got.float().cpu(), ref.float().cpu()
@@ -334,11 +345,20 @@ def test_flash_attention_long_key_kernel(Lk):
 
 @pytest.mark.parametrize("Lq,Lk,B,scale,spike", [(2048, 2048, 1, 1.0, False), (2100, 2100, 1, 1.0, False), (700, 4000, 2, 1.0, False),
                                                  (3000, 2992, 2, 2.0, True), (11440, 11440, 2, 1.0, False)])
-def test_flash_attention_pw4_kernel_is_bit_identical_to_fwd12(Lq, Lk, B, scale, spike, monkeypatch):
-    """The two long-key self-attention kernels (the default 12-wave workgroups and the opt-in 4-wave x 64-query kernel with asm-owned
-    accumulator registers, attn_pw4.hip) perform the same per-query arithmetic in the same order: their outputs must agree BIT FOR BIT -
-    full tiles, ragged last tile and ragged last workgroup, stacked samples, spiked keys that move the deferred softmax maximum late
-    in the sequence, and the bench shape. Any hazard or staging slip in the hand-placed kernel shows up here (and did, four times)."""
+def test_flash_attention_pw4_kernel_is_bit_identical_to_fwd12(Lq, Lk, B, scale, spike):
+    """The product's long-key self-attention kernel (12-wave workgroups, flash_attn_fwd12_kernel) and the DIAGNOSTIC 4-wave x 64-query
+    kernel with asm-owned accumulator registers (tools/diag/attn_pw4.hip - out of the product library since round 4: bit-identical and
+    10 % slower; built by __graft_entry__.build() into tools/diag/libuv_diag.so) perform the same per-query arithmetic in the same
+    order: their outputs must agree BIT FOR BIT - full tiles, ragged last tile and ragged last workgroup, stacked samples, spiked keys
+    that move the deferred softmax maximum late in the sequence, and the bench shape. Two independently scheduled implementations of
+    one arithmetic: any hazard or staging slip in either shows up here (and did, four times)."""
+    import ctypes
+    diag_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "diag", "libuv_diag.so")
+    if not os.path.exists(diag_path):
+        pytest.skip("tools/diag/libuv_diag.so is not built (python tools/diag/build_diag.py)")
+    diag = ctypes.CDLL(diag_path)
+    P_, L_, I_ = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
+    diag.uv_diag_flash_attn_pw4.argtypes = [P_, L_, P_, L_, P_, L_, P_, L_, I_, I_, I_, I_, I_, ctypes.c_float, P_]
     H, D = 24 if Lq > 4096 else 4, 128
     C = H * D
     g = torch.Generator(device=DEV).manual_seed(Lq + Lk)
@@ -349,11 +369,16 @@ def test_flash_attention_pw4_kernel_is_bit_identical_to_fwd12(Lq, Lk, B, scale, 
         k[Lk - 5] *= 9.0
     vt = torch.randn(C, (B - 1) * Lk + (Lk + 63) // 64 * 64, generator=g, device=DEV).to(BF16)
     outs = {}
+    assert "fwd12" in L().attn_kernel_name(Lq, Lk, D, B, H=H)
     for kind in ("fwd12", "pw4"):
-        monkeypatch.setenv("UV_ATTN_LONG", kind)
-        assert (kind == "pw4") == ("pw4" in L().attn_kernel_name(Lq, Lk, D, B, H=H))
         o = torch.full((B * Lq + 8, C), 7.0, dtype=BF16, device=DEV)
-        L().flash_attn(q, k, vt, o, Lq, Lk, H, D, D ** -0.5, batch=B)
+        if kind == "fwd12":
+            L().flash_attn(q, k, vt, o, Lq, Lk, H, D, D ** -0.5, batch=B)
+        else:
+            rc = diag.uv_diag_flash_attn_pw4(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), vt.data_ptr(), vt.stride(0), o.data_ptr(),
+                                             o.stride(0), B, Lq, Lk, H, D, D ** -0.5, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+        torch.cuda.synchronize()
         assert (o[B * Lq:] == 7.0).all(), f"{kind} wrote past Lq"
         outs[kind] = o
     assert torch.isfinite(outs["pw4"].float()).all()
@@ -586,14 +611,24 @@ def _tiny_model(seed=0, **over):
 
 
 def _truth_forward(sd, cfg, *args, **kw):
-    """The oracle with every bf16 rounding removed (fp32 everywhere): the "truth" both implementations approximate."""
+    """The oracle with every bf16 rounding removed (fp32 everywhere): the "truth" both implementations approximate.
+    On the GPU the fp32 SDPA of a long sequence goes through torch's math backend, which materialises heads x L x L scores (71 GB at
+    L = 27 280): there the oracle's attention_core is run a few heads at a time (heads are independent: same function)."""
     from oracle import lora as ora_lora, wan_dit
-    old = wan_dit.BF16
+    old, core = wan_dit.BF16, wan_dit.attention_core
+
+    def core_by_heads(q, k, v, k_lens=None):
+        if q.device.type != "cuda" or q.size(1) * k.size(1) < 2 ** 28:
+            return core(q, k, v, k_lens)
+        return torch.cat([core(q[:, :, h:h + 2], k[:, :, h:h + 2], v[:, :, h:h + 2], k_lens) for h in range(0, q.size(2), 2)], dim=2)
+
     wan_dit.BF16 = ora_lora.BF16 = torch.float32
+    wan_dit.attention_core = core_by_heads
     try:
         return wan_dit.dit_forward(sd, cfg, *args, **kw)
     finally:
         wan_dit.BF16 = ora_lora.BF16 = old
+        wan_dit.attention_core = core
 
 
 def test_dit_tiny_forward_vs_golden():
@@ -852,7 +887,7 @@ def test_embedding_stages_and_head_ti2v5b_width_vs_oracle():
     # 3072 inputs moves an output by ~1e-3 of its size), so the elementwise tolerance is not the informative gate here; the distance
     # to the unrounded result is: HIP must be as close to it as the reference arithmetic is.
     # Measured on MI355X: 38 % inside, max 1.7e-3 of the range, rms to the truth 0.87 x the oracle's own.
-    assert_model_close(out, ref[0], truth[0], frac=0.07, max_rel=2.6e-3, truth_ratio=1.05, name="0-block TI2V-5B: patch embedding + head")
+    assert_model_close(out, ref[0], truth[0], frac=0.31, max_rel=2.1e-3, truth_ratio=1.05, name="0-block TI2V-5B: patch embedding + head")
 
 
 def test_dit_block_ti2v5b_width_vs_golden():
@@ -884,8 +919,8 @@ def test_dit_block_ti2v5b_width_vs_golden():
         wan_dit.BF16 = old
     # at width 3072 the reference's own bf16 roundings put BOTH implementations ~1e-3 (rms) from the truth; the two
     # differ from each other by less than either differs from the truth
-    assert_model_close(out[0], g["out_f32"][0], truth[0], frac=0.62, max_rel=3.2e-3, name="block f32 stream")   # measured 74.5 %, 1.7e-3, 1.003
-    assert_model_close(outb[0], g["out_bf16"][0], frac=0.62, max_rel=3.2e-3, name="block bf16 stream (block 0)")   # measured 74.5 %, 2.1e-3
+    assert_model_close(out[0], g["out_f32"][0], truth[0], frac=0.69, max_rel=2.5e-3, name="block f32 stream")   # measured 74.5 %, 1.7e-3, 1.003
+    assert_model_close(outb[0], g["out_bf16"][0], frac=0.69, max_rel=2.5e-3, name="block bf16 stream (block 0)")   # measured 74.5 %, 2.1e-3
     # fused path: 2 modulation rows + token->row map instead of a per-token table
     from univid_amd.wan.model import _freqs_device
     x = g["x"][0].to(DEV).clone()
@@ -930,7 +965,7 @@ def test_dit_block_ti2v5b_width_1014_tokens_vs_oracle():
         blk.prepare()
         blk._run(xs, Lt, e_rows.reshape(2, -1).to(DEV), tid.to(torch.int32).to(DEV), grid, _freqs_device(freqs, torch.device(DEV)),
                  ctx[0].to(DEV), first_block=False)
-    assert_model_close(xs, ref[0], truth[0], frac=0.77, max_rel=2.7e-3, name="TI2V-5B block, L=1014")   # measured 84.7 %, 1.7e-3, 1.0003
+    assert_model_close(xs, ref[0], truth[0], frac=0.81, max_rel=2.1e-3, name="TI2V-5B block, L=1014")   # measured 84.7 %, 1.7e-3, 1.0003
 
 
 def test_dit_block_ti2v5b_width_full_length_vs_cpu_oracle():
@@ -969,13 +1004,13 @@ def test_dit_block_ti2v5b_width_full_length_vs_cpu_oracle():
         blk.prepare()
         blk._run(xs, Lt, e_rows.reshape(2, -1).to(DEV), tid.to(torch.int32).to(DEV), grid, _freqs_device(freqs, torch.device(DEV)),
                  ctx[0].to(DEV), first_block=False)
-    assert_model_close(xs, ref[0], truth[0], frac=0.79, max_rel=4.3e-3, name="TI2V-5B block, L=11440 (CPU oracle)")   # measured 86.2 %, 2.8e-3, 1.0008
+    assert_model_close(xs, ref[0], truth[0], frac=0.83, max_rel=3.4e-3, name="TI2V-5B block, L=11440 (CPU oracle)")   # measured 86.2 %, 2.8e-3, 1.0008
 
 
 def SAMPLER10_GATE(what):
     # 10 steps take 5x larger steps than 50. Measured on MI355X (profiles/r02_parity_margins.json): noise_pred 1.9e-3 (step 0) ->
     # 3.3e-3 (step 9), latents 1.4e-5 -> 5.2e-4. Gates = 1.5 x the largest measured value.
-    return 5e-3 if what.startswith("noise_pred") else 8e-4
+    return 4.0e-3 if what.startswith("noise_pred") else 6.3e-4      # x 1.2 since round 4
 
 
 def test_sampler_trajectories_vs_golden():
@@ -1001,6 +1036,41 @@ def test_sampler_trajectories_vs_golden():
             assert v < SAMPLER10_GATE(k), f"{mode} {k}: rel rms {v:.3e}"
         if mode == "i2v":
             assert torch.equal(final[:, 0].cpu(), g["z"][:, 0]), "i2v must keep the first latent frame pinned to z"
+
+
+def test_graph_runner_is_not_reused_for_versionless_contexts():
+    """Round-3 advisor finding: tensors created under torch.inference_mode() have no version counter, so an in-place refill of a
+    preallocated prompt-embeds buffer between two generations is invisible to the HIP-graph runner's key; a reused runner would replay
+    the OLD prompt's cross-attention K / V^T. Two graph-mode denoise calls under inference_mode with the context changed in place must
+    each equal their eager run; a repeated call on version-counted, unchanged contexts still reuses the captured graph."""
+    from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+    g = load_golden("sampler_tiny")
+    cfg, sd, m = _tiny_model(g["seed"])
+    pipe = WanTI2V(TI2VConfig, model=m, device=DEV)
+    args = (2, g["shift"], g["guide_scale"])
+    with torch.inference_mode():
+        noise = g["noise"].to(DEV)
+        ctx, ctxn = [g["ctx"].to(DEV).clone()], [g["ctx_null"].to(DEV).clone()]
+        a_graph = pipe.denoise(noise, ctx, ctxn, *args, graph=True).clone()
+        r1 = pipe._runner
+        assert r1 is not None
+        a_eager = pipe.denoise(noise, ctx, ctxn, *args, graph=False)
+        assert torch.equal(a_graph, a_eager)
+        ctx[0].mul_(-0.5)                                  # same storage, same (absent) version: a new prompt in the old buffer
+        b_graph = pipe.denoise(noise, ctx, ctxn, *args, graph=True).clone()
+        assert pipe._runner is not r1, "a versionless context must not reuse the previous call's captured graph"
+        b_eager = pipe.denoise(noise, ctx, ctxn, *args, graph=False)
+        assert torch.equal(b_graph, b_eager), "graph replay used the previous prompt's context"
+        assert not torch.equal(b_graph, a_graph)
+    with torch.no_grad():                                  # version-counted tensors: unchanged contexts replay the same graph
+        ctx2, ctxn2 = [g["ctx"].to(DEV).clone()], [g["ctx_null"].to(DEV).clone()]
+        c1 = pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, graph=True).clone()
+        r2 = pipe._runner
+        c2 = pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, graph=True)
+        assert pipe._runner is r2 and torch.equal(c1, c2) and torch.equal(c1, a_graph)
+        ctx2[0].mul_(-0.5)                                 # in-place edit bumps the version: new key, recapture
+        c3 = pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, graph=True)
+        assert pipe._runner is not r2 and torch.equal(c3, b_graph)
 
 
 def test_sampler_dpmpp_trajectories_vs_golden():
@@ -1072,7 +1142,7 @@ def test_sampler_50_step_trajectories_vs_golden():
 def SAMPLER50_GATE(what):
     # measured on MI355X (profiles/r02_parity_margins.json): noise_pred 1.9e-3 (step 0) growing to 3.0e-3 (step 49) - CFG's x5
     # on the DiT's bf16 noise -, latents 2.5e-6 growing to 2.1e-4 over the 50 steps. Gates = 1.5 x the largest measured value.
-    return 4.6e-3 if what.startswith("noise_pred") else 3.2e-4
+    return 3.7e-3 if what.startswith("noise_pred") else 2.6e-4      # x 1.2 since round 4
 
 
 def test_dit_stack_ti2v5b_width_depth_vs_oracle():
@@ -1116,7 +1186,7 @@ def test_dit_stack_ti2v5b_width_depth_vs_oracle():
 
 # measured on MI355X (profiles/r03_parity_margins.json): inside 94.6 / 87.6 / 75.7 / 53.1 %, max error 3.8e-3 / 3.9e-3 / 3.8e-3 / 9.7e-4 of the
 # range, rms-vs-truth ratio 0.9995-1.0000; gates = 1.5 x the measured outside fraction / maximum
-FULL_LENGTH_GATE = {1: (0.919, 5.7e-3), 2: (0.814, 5.9e-3), 4: (0.636, 5.7e-3), "out": (0.296, 1.5e-3)}
+FULL_LENGTH_GATE = {1: (0.93, 4.6e-3), 2: (0.85, 4.8e-3), 4: (0.70, 4.6e-3), "out": (0.44, 1.2e-3)}      # measured x 1.2 (round 4)
 
 
 def test_dit_stack_full_length_vs_cpu_oracle():
@@ -1231,8 +1301,9 @@ def test_dit_trained_weight_regime_stress_vs_oracle():
 # (min inside fraction, max |err| / range). Measured on MI355X (profiles/r03_parity_margins.json): in this regime the bf16 roundings of BOTH
 # implementations are amplified (rms distance to the no-rounding truth 0.046 / 0.24 / 0.041 for the oracle, 0.9997 / 0.9952 / 0.9954 of
 # that for the HIP path), so only 21 % / 3.6 % / 4.3 % of the elements agree to rtol 1e-3 / atol 1e-4 and the gate that carries the test
-# is the truth ratio (<= 1.02); max error 4.4e-3 / 1.5e-2 / 2.1e-2 of the range, gates = x 1.5.
-STRESS_GATE = {1: (0.10, 6.6e-3), 3: (0.0, 2.3e-2), "out": (0.0, 3.2e-2)}
+# is the truth ratio (<= 1.02); max error 4.4e-3 / 1.5e-2 / 2.1e-2 of the range, gates = x 1.2; the inside fractions get non-zero floors
+# (round-3 verdict: a gate of 0.0 asserts nothing): 0.15 / 0.02 / 0.02 against the measured 0.209 / 0.036 / 0.043.
+STRESS_GATE = {1: (0.15, 5.3e-3), 3: (0.02, 1.85e-2), "out": (0.02, 2.6e-2)}
 
 
 def test_vae_heavy_tailed_input_stress_vs_oracle():
@@ -1275,19 +1346,22 @@ def test_vae_heavy_tailed_input_stress_vs_oracle():
 # 94.8 / 87.6 / 75.4 / 60.5 % after 1 / 2 / 4 / 8 blocks and 41 % at the head output, max error 2.4-2.8e-3 of the range, relative
 # rms vs the oracle 5.0e-4 x sqrt(depth) (a random walk of bf16 rounding flips), rms-vs-truth ratio 0.9999-1.0017 at every depth.
 # Gates = 1.5 x the measured outside fraction / max error.
-DEPTH_GATE = {1: (0.92, 3.7e-3), 2: (0.81, 3.7e-3), 4: (0.63, 3.6e-3), 8: (0.41, 4.2e-3), "out": (0.27, 2.2e-3)}
+DEPTH_GATE = {1: (0.93, 2.9e-3), 2: (0.85, 3.0e-3), 4: (0.70, 3.0e-3), 8: (0.52, 4.2e-3), "out": (0.34, 1.8e-3)}      # measured x 1.2 (round 4)
 
 
-# measured on MI355X (profiles/r02_parity_margins.json) x 1.5: (latent shape, tokens, blocks, min inside fraction, max |err| / range)
-EAGER_SHAPES = {"config2": ((48, 13, 30, 52), 5070, 2, 0.15, 4.5e-3), "bench": ((48, 13, 44, 80), 11440, 2, 0.15, 4.5e-3),
-                "bench30": ((48, 13, 44, 80), 11440, 30, 0.13, 5.7e-3)}
+# measured on MI355X (profiles/r02_parity_margins.json, r03_parity_margins.json) x 1.2 (inside fraction / 1.2; 1.2 x the larger max error
+# of the two rounds): (latent shape, tokens, blocks, min inside fraction, max |err| / range). "default" = UniVid's own default workload,
+# 121 frames 704 x 1280 (inference.py:48-50), first measured in round 4.
+EAGER_SHAPES = {"config2": ((48, 13, 30, 52), 5070, 2, 0.19, 3.5e-3), "bench": ((48, 13, 44, 80), 11440, 2, 0.19, 3.7e-3),
+                "bench30": ((48, 13, 44, 80), 11440, 30, 0.16, 5.6e-3), "default": ((48, 31, 44, 80), 27280, 2, 0.17, 4.4e-3)}
 
 
-@pytest.mark.parametrize("which", ["config2", "bench", "bench30"])
+@pytest.mark.parametrize("which", ["config2", "bench", "bench30", "default"])
 def test_real_shapes_vs_eager_oracle(which):
     """BASELINE config 2 at its REAL shape (49 frames 480x832 -> latent [48,13,30,52], L = 5 070) and the BENCH shape
     (49 frames 704x1280 -> [48,13,44,80], L = 11 440) at TI2V-5B width with two blocks, and the WHOLE 30-block TI2V-5B model at
-    the bench shape ("bench30": the full configuration bench.py times), VALUE-checked on every element. The CPU oracle
+    the bench shape ("bench30": the full configuration bench.py times), and UniVid's OWN DEFAULT workload ("default": 121 frames
+    704 x 1280, inference.py:48-50 -> latent [48,31,44,80], L = 27 280, two blocks), VALUE-checked on every element. The CPU oracle
     would need minutes per block here, so the checker is the ORACLE TEXT executed by torch-ROCm eager on the same GPU
     (rocBLAS/hipBLASLt + SDPA kernels: the reference's own eager path is exactly this kind of second implementation), once as
     written (bf16 rounding points) and once with every rounding removed (truth). Plus the size-independent properties: padding
@@ -1363,7 +1437,7 @@ def test_config2_full_run_50_steps_vs_eager_oracle():
 
 # (noise_pred, latent). Measured on MI355X (profiles/r02_parity_margins.json): noise_pred 1.4-1.6e-2 at every step (CFG's x5 on the
 # 3.5e-3 difference between the two 30-block forwards), latents 8e-5 (step 0) -> 3.0e-3 (step 49). Gates = 1.5 x the largest.
-CONFIG2_RUN_GATE = (2.5e-2, 4.5e-3)
+CONFIG2_RUN_GATE = (2.0e-2, 3.6e-3)      # measured 1.63e-2 / 2.97e-3 (rounds 2 and 3) x 1.2
 
 
 def test_full_model_i2v_and_text_weight_hook_vs_eager_oracle():
@@ -1417,7 +1491,7 @@ def test_full_model_i2v_and_text_weight_hook_vs_eager_oracle():
 
 
 # measured on MI355X (profiles/r02_parity_margins.json): i2v 7.5e-3, hook 7.6e-3 after 8 steps (CFG x5 on 3.5e-3 per forward); x 1.5
-FULL_VARIANT_GATE = 1.15e-2
+FULL_VARIANT_GATE = 9.2e-3      # x 1.2 (round 4)
 
 
 def test_text_weight_hook_path_matches_oracle():
@@ -1591,7 +1665,7 @@ def test_lora_adapter_directory_tiny_model_vs_unmerged_oracle(tmp_path):
     # Merged and un-merged projections round differently (one bf16 rounding of W + dW against separate roundings of the two
     # branches), and this adapter is deliberately large: measured 63 % inside, max 1.2e-3 of the range - and the merged HIP result
     # is as close to the unrounded truth as PEFT's un-merged arithmetic is (rms ratio 0.985), which is the gate that matters.
-    assert_model_close(got, ref, truth, frac=0.45, max_rel=1.9e-3, truth_ratio=1.05, name="tiny DiT + LoRA (merged on HIP vs un-merged oracle)")
+    assert_model_close(got, ref, truth, frac=0.55, max_rel=1.5e-3, truth_ratio=1.05, name="tiny DiT + LoRA (merged on HIP vs un-merged oracle)")
     # the adapter's EFFECT is reproduced, not just the base model: (adapted - base) on HIP vs on the oracle
     d_hip, d_ref = (got - base).cpu(), ref - g["out_one"]
     rel = float((d_hip - d_ref).pow(2).mean().sqrt() / d_ref.pow(2).mean().sqrt())
@@ -1652,7 +1726,7 @@ def test_lora_adapter_ti2v5b_width_block_vs_unmerged_oracle(tmp_path):
     effect = _rel_rms(ref[0] - x[0], ref_base[0] - x[0])
     assert effect > 0.05, f"adapter effect on the block's update only {effect:.3f}"
     # measured: 60 % inside, max 2.7e-3 of the range (the un-adapted block: 84.7 %, 1.7e-3)
-    assert_model_close(xs, ref[0], truth[0], frac=0.40, max_rel=4e-3, truth_ratio=1.05, name="TI2V-5B block + LoRA r16 (merged on HIP vs un-merged oracle)")
+    assert_model_close(xs, ref[0], truth[0], frac=0.51, max_rel=3.2e-3, truth_ratio=1.05, name="TI2V-5B block + LoRA r16 (merged on HIP vs un-merged oracle)")
 
 
 def test_model_errors_are_loud():
@@ -1911,7 +1985,7 @@ def test_conv3d_kernel_geometries(entry):
 
 
 @pytest.mark.parametrize("entry", ["uv_conv3d_f32", "uv_conv3d_bf16x6"])
-def test_conv3d_halo_kernel_geometries(entry, monkeypatch):
+def test_conv3d_halo_kernel_geometries(entry):
     """The LDS-halo kernel of the 3x3(x3) stride-1 convolutions (conv3d_halo.hip; vae2_2.py:17-42 as ResidualBlock uses it) against
     F.conv3d AND against the gather kernel it replaces (UV_CONV_HALO=0), forced on for launches too small to pick it by themselves:
     frames that are not whole 8 x 32 patches, one and several patches per frame, causal zero frames in front, two channel blocks
@@ -1923,7 +1997,7 @@ def test_conv3d_halo_kernel_geometries(entry, monkeypatch):
     g = torch.Generator().manual_seed(14)
 
     def run(x_cl, w, b, Tout, Hout, Wout, halo, resid=None, t_off=0, up=0):
-        monkeypatch.setenv("UV_CONV_HALO", "1" if halo else "0")
+        _lib.set_option(_lib.OPT_CONV_HALO, 1 if halo else 0)
         T, H, W, C = x_cl.shape
         co, ci, kt, kh, kw_ = w.shape
         wp = w.permute(0, 2, 3, 4, 1).reshape(co, -1).contiguous().to(DEV)
@@ -2065,6 +2139,110 @@ def test_full_size_attention_properties():
     assert ((o2.float() * 2 - out.float()).abs() <= 2 * bf16_ulp(out.float().cpu()).to(DEV)).all()
 
 
+def test_default_workload_attention_and_gemm_properties():
+    """UniVid's default workload (inference.py:48-50: 121 frames 704 x 1280 -> L = 27 280 tokens, the CFG pair stacked = 54 560 rows,
+    24 heads x 128): self-attention of V = 1 is exactly 1 over every row of both samples (softmax rows sum to 1; 27 280 = 426 key tiles
+    + a ragged 16-key tile), sampled query rows against an fp64 softmax, linearity in V, and sampled rows of the three GEMM shapes
+    (3072 -> 3072 bf16, 3072 -> 14336 GELU, 14336 -> 3072 gated fp32 residual) at 54 560 rows - whole rounds of the persistent kernel
+    plus the leftover-row strip - against fp64 dot products."""
+    from univid_amd._lib import EPI_BF16, EPI_GATE_RESID_F32
+    Lq = Lk = 27280
+    H, D, B = 24, 128, 2
+    C = H * D
+    g = torch.Generator(device=DEV).manual_seed(27)
+    q = torch.randn(B * Lq, C, device=DEV, generator=g).to(BF16)
+    k = torch.randn(B * Lk, C, device=DEV, generator=g).to(BF16)
+    v = torch.randn(B * Lk, C, device=DEV, generator=g).to(BF16)
+    cols = (B - 1) * Lk + (Lk + 63) // 64 * 64
+    vt = torch.zeros(C, cols, dtype=BF16, device=DEV)
+    vt[:, :B * Lk] = v.t()
+    out = torch.empty(B * Lq, C, dtype=BF16, device=DEV)
+    L().flash_attn(q, k, vt, out, Lq, Lk, H, D, D ** -0.5, batch=B)
+    assert torch.isfinite(out.float()).all()
+    rows = torch.tensor([0, 31, 32, 383, 384, 4097, 13000, 27247, 27279], device=DEV)
+    for b in range(B):
+        for hd in (0, 13, 23):
+            sl = slice(hd * D, (hd + 1) * D)
+            qs = q[b * Lq + rows][:, sl].double()
+            ks, vs = k[b * Lk:(b + 1) * Lk, sl].double(), v[b * Lk:(b + 1) * Lk, sl].double()
+            truth = torch.softmax(qs @ ks.t() / math.sqrt(D), -1) @ vs
+            got = out[b * Lq + rows][:, sl].double()
+            tol = 3 * bf16_ulp(truth.float().cpu()).to(DEV) + 2e-3 * truth.abs().max()
+            assert ((got - truth).abs() <= tol).all(), f"sample {b} head {hd}: max err {float((got - truth).abs().max()):.3e}"
+    ones = torch.ones_like(vt)
+    ones[:, B * Lk:] = 7.0                                   # the ragged tile's padding columns must never be attended
+    o1 = torch.empty_like(out)
+    L().flash_attn(q, k, ones, o1, Lq, Lk, H, D, D ** -0.5, batch=B)
+    assert (o1.float() - 1).abs().max() <= 2 ** -7
+    vt2 = (vt.float() * 0.5).to(BF16)
+    L().flash_attn(q, k, vt2, o1, Lq, Lk, H, D, D ** -0.5, batch=B)
+    assert ((o1.float() * 2 - out.float()).abs() <= 2 * bf16_ulp(out.float().cpu()).to(DEV)).all()
+    del ones, o1, vt2, vt, v, k
+    # GEMMs at 54 560 rows: sampled rows (first / last rows of the persistent part, rows of the leftover strip) against fp64
+    M = B * Lq
+    rows = torch.tensor([0, 255, 256, 30000, 54271, 54272, 54400, 54559], device=DEV)
+    w = (torch.randn(14336, C, device=DEV, generator=g) * 0.02).to(BF16)
+    y = torch.empty(M, 14336, dtype=BF16, device=DEV)
+    L().gemm_bf16(q, w, None, y, EPI_BF16)
+    truth = q[rows].double() @ w.double().t()
+    assert ((y[rows].double() - truth).abs() <= bf16_ulp(truth.float()).double() + 1e-6).all(), "ffn.0-shape GEMM rows"
+    w2 = (torch.randn(C, 14336, device=DEV, generator=g) * 0.02).to(BF16)
+    x = torch.randn(M, C, device=DEV, generator=g)
+    x0 = x[rows].clone()
+    gate = torch.randn(2, C, device=DEV, generator=g)
+    tid = (torch.arange(M, device=DEV) >= Lq).to(torch.int32)           # sample 0 -> gate row 0, sample 1 -> row 1
+    L().gemm_bf16(y, w2, None, x, EPI_GATE_RESID_F32, gate=gate, gate_tid=tid)
+    acc = y[rows].double() @ w2.double().t()
+    gr = gate[tid[rows].long()].double()
+    want = x0.double() + acc.to(BF16).double() * gr                     # the epilogue rounds the product to bf16 first (model.py:255)
+    d = (x[rows].double() - want).abs()
+    tol = (bf16_ulp(acc.float()).double() + 2e-5 * acc.abs().max()) * gr.abs() + 1e-6
+    assert (d <= tol).all() and (d <= 1e-6).float().mean() > 0.999, f"ffn.2-shape gated residual rows: max err {float(d.max()):.3e}"
+    wq = (torch.randn(C, C, device=DEV, generator=g) * 0.02).to(BF16)
+    yq = torch.empty(M, C, dtype=BF16, device=DEV)
+    L().gemm_bf16(q, wq, None, yq, EPI_BF16)
+    truth = q[rows].double() @ wq.double().t()
+    assert ((yq[rows].double() - truth).abs() <= bf16_ulp(truth.float()).double() + 1e-6).all(), "q-shape GEMM rows"
+
+
+def test_default_workload_vae_decode_properties():
+    """UniVid's default clip through the VAE decoder: latent [48, 31, 44, 80] -> 121 x 704 x 1280 RGB (inference.py:48-50,
+    vae2_2.py:812-839), exact-f32 mode, with the size-independent properties of test_vae_config4_full_clip_encode_decode_properties:
+    shape, finiteness, clamp, first frame == decoding the first latent frame alone, frames 0..12 == decoding latents 0..3 alone
+    (causal decoder), pass length 1 == 4 on the first three latent frames; and the f32-grade bf16x6 mode within rtol 1e-3 / atol 1e-4
+    of the exact mode on every element of the 121 frames. The memory high-water mark of the decode is recorded."""
+    from oracle import wan_vae
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    sd = wan_vae.make_state_dict(wan_vae.FULL_CFG, 2)
+    vae = Wan2_2_VAE(device=DEV, precision="fp32")
+    vae.model.load_state_dict(sd)
+    g = torch.Generator(device=DEV).manual_seed(47)
+    z = torch.randn(48, 31, 44, 80, generator=g, device=DEV)
+    with torch.no_grad():
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        out = vae.decode([z])[0]
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        assert out.shape == (3, 121, 704, 1280) and torch.isfinite(out).all()
+        assert out.abs().max() <= 1.0
+        first = vae.decode([z[:, :1]])[0]
+        assert torch.equal(first, out[:, :1]), "first frame of the whole-clip decode != decoding the first latent frame alone"
+        head = vae.decode([z[:, :4]])[0]
+        assert torch.equal(head, out[:, :13]), "causal decoder: frames 0..12 must not depend on latent frames 4.."
+        vae1 = Wan2_2_VAE(device=DEV, precision="fp32", frames_per_pass=1)
+        vae1.model.load_state_dict(sd)
+        assert torch.equal(vae1.decode([z[:, :3]])[0], head[:, :9]), "pass length 1 vs 4"
+        del vae1, first, head
+        vae6 = Wan2_2_VAE(device=DEV, precision="bf16x6")
+        vae6.model.load_state_dict(sd)
+        out6 = vae6.decode([z])[0]
+        d = (out6 - out).abs()
+        bad = int((d > 1e-4 + 1e-3 * out.abs()).sum())
+        record_margin("default workload VAE decode 121x704x1280", peak_GiB=peak, bf16x6_vs_f32_max_abs=float(d.max()), outside=bad)
+        assert bad == 0, f"bf16x6 vs exact f32: {bad} of {out.numel()} elements outside rtol 1e-3 / atol 1e-4"
+
+
 def test_full_size_dit_stack_equals_sequential():
     """Two TI2V-5B-width blocks at the bench sequence length: the stacked CFG pair is bit-identical to two single forwards,
     everything finite, and the result depends on the context (cond != uncond)."""
@@ -2160,14 +2338,22 @@ def _sp_gpu_worker(rank, world, port, q, nccl=False):
                 refused = True
         ok = torch.equal(sharded[0], plain[0]) and torch.equal(sharded[1], plain[1]) and torch.equal(single, plain[1])
         if rank == 0:
-            # not only sharded == plain (HIP vs HIP): the SHARDED forward against the pinned CPU oracle on the golden inputs (two
-            # timesteps in one sample, i.e. the i2v form) and against the no-rounding truth run, with the tiny-DiT gates
-            from oracle import wan_dit
-            with torch.no_grad():
-                ref = wan_dit.dit_forward(sd, cfg, [g["x"]], g["t_two"], [g["ctx"]], Lt)[0]
-                truth = _truth_forward(sd, cfg, [g["x"]], g["t_two"], [g["ctx"]], Lt)[0]
-            assert torch.equal(ref, g["out_two"]) or cfg["num_heads"] != 4 or True   # (the golden was generated with the same 4-head config)
-            assert_model_close(sharded[0], ref, truth, name=f"sequence-parallel forward, {world} ranks, vs CPU oracle")
+            # not only sharded == plain (HIP vs HIP): the SHARDED forward against the PINNED golden output (oracle == reference bit for
+            # bit when the fixture was generated; two timesteps in one sample, i.e. the i2v form) and against the no-rounding truth
+            # run, with the tiny-DiT gates. The oracle re-run on THIS host must reproduce the golden up to the last-place differences
+            # of oneDNN's bf16 kernels between CPU generations (bit-identical in the build container: tests/test_oracle_golden.py).
+            try:
+                from oracle import wan_dit
+                with torch.no_grad():
+                    here = wan_dit.dit_forward(sd, cfg, [g["x"]], g["t_two"], [g["ctx"]], Lt)[0]
+                    truth = _truth_forward(sd, cfg, [g["x"]], g["t_two"], [g["ctx"]], Lt)[0]
+                ref = g["out_two"]
+                drift = _rel_rms(here, ref)
+                assert drift <= 1e-3, f"the CPU oracle on this host is {drift:.2e} rel rms from the pinned golden"
+                assert_model_close(sharded[0], ref, truth, name=f"sequence-parallel forward, {world} ranks, vs pinned golden")
+            except BaseException as ex:      # report instead of leaving the parent to wait for the queue timeout
+                q.put((rank, False, f"rank 0 check failed: {ex!r}"[:500], float("nan")))
+                raise
         q.put((rank, bool(ok), refused, float((sharded[0] - plain[0]).abs().max())))
     finally:
         dist.destroy_process_group()

@@ -10,9 +10,25 @@ H, D = 24, 128
 C = H * D
 
 
+import ctypes
+_diag_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag", "libuv_diag.so")
+if not os.path.exists(_diag_path):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag"))
+    import build_diag
+    build_diag.build()
+_diag = ctypes.CDLL(_diag_path)
+_P, _L, _I = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
+_diag.uv_diag_flash_attn_pw4.argtypes = [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, ctypes.c_float, _P]
+
+
 def run(kind, q, k, vt, out, L, Lk, B):
-    os.environ["UV_ATTN_LONG"] = kind
-    _lib.flash_attn(q, k, vt, out, L, Lk, H, D, 1 / math.sqrt(D), batch=B)
+    """fwd12 = the product's kernel through the C ABI; pw4 = the diagnostic kernel of tools/diag/libuv_diag.so"""
+    if kind == "pw4":
+        rc = _diag.uv_diag_flash_attn_pw4(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), vt.data_ptr(), vt.stride(0), out.data_ptr(),
+                                          out.stride(0), B, L, Lk, H, D, 1 / math.sqrt(D), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+    else:
+        _lib.flash_attn(q, k, vt, out, L, Lk, H, D, 1 / math.sqrt(D), batch=B)
 
 
 def make(L, Lk, B, seed, scale=1.0, spike=False):

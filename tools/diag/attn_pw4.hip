@@ -1,3 +1,8 @@
+// DIAGNOSTIC KERNEL - not part of libunivid_hip.so since round 4 (it is bit-identical to and 10 % slower than the product's
+// flash_attn_fwd12_kernel; it stays in tools/diag/ as a second, independently scheduled implementation of the same arithmetic:
+// tools/diag/build_diag.py builds tools/diag/libuv_diag.so with the C entry uv_diag_flash_attn_pw4, the GPU test
+// test_flash_attention_pw4_kernel_is_bit_identical_to_fwd12 and tools/attn_ab.py call it).
+//
 // Flash attention forward for LONG key sequences (head_dim 128, bf16): the 4-wave, one-wave-per-SIMD, 64-queries-per-wave
 // structure of the CDNA4 playbook, with the whole 512-entry register file per wave.
 //
@@ -29,7 +34,7 @@
 //     the decision's update path in the start phase, O^T *= alpha at the two points of phase 2 where the reference order has it.
 // tools/diag/pw4_audit.py checks the compiled ISA (no compiler access to the asm-owned AGPRs, no VALU write in front of an MFMA
 // that reads it); tests/test_host_logic.py runs it.
-#include "attn_args.h"
+#include "attn_args.h"      // univid_amd/csrc (-I): argument block and constants shared with attention.hip
 #include <type_traits>
 #include <utility>
 
@@ -599,10 +604,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     });
 }
 
-int uv_launch_attn_pw4(const AttnArgs& a0, hipStream_t st) {
+static int uv_launch_attn_pw4(const AttnArgs& a0, hipStream_t st) {
     AttnArgs a = a0;
     a.q_blocks = (a.Lq + 255) / 256;
     a.n12 = 0;
     hipLaunchKernelGGL(flash_attn_pw4_kernel, dim3(a.q_blocks * a.H * a.batch), dim3(256), 0, st, a);
     return 0;
 }
+
+#ifndef UV_PW4_DIAG
+// C entry of tools/diag/libuv_diag.so: the argument list of uv_flash_attn_bf16 (include/univid_hip.h). Returns 0, or -1 for a shape this
+// kernel does not serve (head_dim 128, bf16, 32-bit lane offsets).
+extern "C" int uv_diag_flash_attn_pw4(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                                      int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream) {
+    if (!q || !k || !vt || !out || head_dim != 128 || Lq <= 0 || Lk <= 0 || H <= 0 || batch <= 0) return -1;
+    if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || 128 * ldvt >= (1L << 30) || 64 * ldk >= (1L << 30)) return -1;
+    if (ldvt < (long)(batch - 1) * Lk + (long)((Lk + 63) / 64) * 64 || (batch > 1 && Lk % 8)) return -1;
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
+    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
+    a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = batch; a.n12 = 0; a.q_blocks = 0;
+    a.scale_log2 = softmax_scale * 1.4426950408889634f;
+    uv_launch_attn_pw4(a, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+void uv_set_error(const char*, ...) {}
+int uv_option(int) { return 0; }
+#endif

@@ -1,7 +1,9 @@
 """Static audit of the hand-placed attention kernel's ISA (developer tool + CPU test): hipcc knows nothing of the instructions inside
 an asm statement, so it neither pads hazards in front of them nor keeps its own spill traffic out of the accumulator registers the
-statements own. Compiles univid_amd/csrc/attn_pw4.hip to assembly and checks
-  1. no compiler-generated access (v_accvgpr_*, scratch reload) to a[0:191] outside ;;#ASMSTART / ;;#ASMEND,
+statements own. Compiles tools/diag/attn_pw4.hip to assembly and checks
+  1. no compiler-generated access (v_accvgpr_*, scratch reload) to the asm-owned a[0:215] (O, Q and BOTH fragment rings: K a192-203,
+     V^T a204-215 - fragments are issued in one statement and used in a later one, so their registers must survive in between; the
+     bound is read from the kernel's own clobber list UV_ACL_ALL) outside ;;#ASMSTART / ;;#ASMEND,
   2. no vector-ALU write of a register within two wait states in front of an asm MFMA that reads it (VALU write -> MFMA source
      operand needs wait states; an s_waitcnt or any other instruction counts one, s_nop N counts N + 1).
 Prints the findings; exit status 1 if there are any."""
@@ -13,11 +15,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 def compile_to_asm(out):
     sys.path.insert(0, ROOT)
     from univid_amd import build
-    src = os.path.join(build.CSRC, "attn_pw4.hip")
-    cmd = [build._hipcc(), *build.FLAGS, *build.FILE_FLAGS.get("attn_pw4.hip", []), "-S", "--cuda-device-only", "-o", out, src]
+    src = os.path.join(ROOT, "tools", "diag", "attn_pw4.hip")
+    cmd = [build._hipcc(), *build.FLAGS, *build.DIAG_PW4_FLAGS, "-I", build.CSRC, "-S", "--cuda-device-only", "-o", out, src]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError(r.stderr[-3000:])
+
+
+def owned_agprs(src):
+    """Number of accumulator registers the kernel's asm statements own = entries of its UV_ACL_ALL clobber list (a0 .. a215)."""
+    m = re.search(r"#define UV_ACL_ALL (.*)", open(src).read())
+    return 1 + max(int(x) for x in re.findall(r'"a(\d+)"', m.group(1)))
+
+
+OWNED = owned_agprs(os.path.join(ROOT, "tools", "diag", "attn_pw4.hip"))      # 216: a0 .. a215
 
 
 def regs(tok):
@@ -48,10 +59,10 @@ def audit(path):
             m = re.search(r"v_accvgpr_(write|read)_b32 (\S+), (\S+)", t)
             if m:
                 a = (m.group(2) if m.group(1) == "write" else m.group(3)).strip(",")
-                if a.startswith("a") and int(a[1:]) < 192:
+                if a.startswith("a") and int(a[1:]) < OWNED:
                     findings.append(f"line {i + 1}: compiler touches asm-owned {a}: {t}")
             m = re.search(r"scratch_load_dword\w* a(\d+)", t)
-            if m and int(m.group(1)) < 192:
+            if m and int(m.group(1)) < OWNED:
                 findings.append(f"line {i + 1}: compiler reloads into asm-owned a{m.group(1)}: {t}")
     for k, (ln, t, ia) in enumerate(real):
         if not t.startswith("v_mfma"):

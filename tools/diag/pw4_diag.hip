@@ -1,10 +1,10 @@
 // Diagnostic build of the 4-wave x 64-query self-attention kernel (developer tool; not part of the library): compiles
-// univid_amd/csrc/attn_pw4.hip with -DUV_PW4_DIAG (in-kernel s_memtime / s_memrealtime stamps around the main loop, timing-only
+// tools/diag/attn_pw4.hip with -DUV_PW4_DIAG (in-kernel s_memtime / s_memrealtime stamps around the main loop, timing-only
 // ablations -DUV_PW4_ABL=<bits>) and runs it on random data at the DiT's self-attention shape. Prints wall time per launch,
 // stamped cycles per key-tile iteration (64 MFMAs per wave) and the clock the chip held in the loop.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DUV_PW4_DIAG [-DUV_PW4_ABL=n] -I univid_amd/csrc \
 //         tools/diag/pw4_diag.hip -o tools/diag/pw4_diag_<n>
-#include "../../univid_amd/csrc/attn_pw4.hip"
+#include "attn_pw4.hip"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>

@@ -14,7 +14,7 @@ for name, M, N, K, epi in (("q", 22880, 3072, 3072, EPI_BF16), ("ffn.0", 22880, 
     res = {gm: [] for gm in (2, 4, 8, 16, 32)}
     for r in range(5):
         for gm in res:
-            os.environ["UV_GEMM_GM"] = str(gm)
+            _lib.set_option(_lib.OPT_GEMM_GM, int(gm))
             for _ in range(2):
                 _lib.gemm_bf16(A, W, None, out, epi)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -15,7 +15,7 @@ outs = {}
 with torch.no_grad():
     for r in range(rounds + 1):
         for h in ("0", "1"):
-            os.environ["UV_CONV_HALO"] = h
+            _lib.set_option(_lib.OPT_CONV_HALO, int(h))
             torch.cuda.synchronize(); t0 = time.perf_counter()
             v = vae.decode([z])[0]
             torch.cuda.synchronize(); dt = time.perf_counter() - t0

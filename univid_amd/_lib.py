@@ -22,6 +22,9 @@ SIGNATURES = {
     "uv_last_error": [],
     "uv_build_id": [],
     "uv_device_arch": [_c.c_char_p, _I],
+    "uv_set_option": [_I, _I],
+    "uv_get_option": [_I, _c.POINTER(_I)],
+    "uv_reset_options": [],
     "uv_gemm_bf16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
     "uv_gemm_f16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
     "uv_gemm_f32_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _P],
@@ -70,6 +73,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"uv_last_error": _c.c_char_p, "uv_build_id": _c.c_char_p}
 
+OPT_CONV_HALO, OPT_GEMM_GM, OPT_ATTN_CUT = range(3)      # include/univid_hip.h: UV_OPT_*
 EPI_BF16, EPI_GELU_BF16, EPI_F32_FROM_BF16, EPI_RESID_F32, EPI_GATE_RESID_F32, EPI_BF16_T = range(6)
 
 _lib = None
@@ -138,6 +142,25 @@ def init(device=None):
     return lib
 
 
+def set_option(key, value):
+    """uv_set_option: explicit developer switch (A/B tools, tests); the library never reads the environment."""
+    lib = load()
+    if lib.uv_set_option(int(key), int(value)) != 0:
+        raise UnividHipError(lib.uv_last_error().decode())
+
+
+def get_option(key):
+    lib = load()
+    v = _I(0)
+    if lib.uv_get_option(int(key), ctypes.byref(v)) != 0:
+        raise UnividHipError(lib.uv_last_error().decode())
+    return v.value
+
+
+def reset_options():
+    load().uv_reset_options()
+
+
 class _DevPtr(_c.c_void_p):
     """A device pointer that remembers which GPU it lives on, so `call` can make that GPU current for the launch."""
     dev = None
@@ -166,6 +189,7 @@ def ptr(t):
 # recorded on the launch stream; PROFILE_ALL times every entry point. Off (None) in normal use.
 PROFILE = None
 PROFILE_ALL = False
+CALL_COUNT = 0          # entry-point launches since import (bench.py reports launches per step)
 
 
 def call(name, *args, flops=0):
@@ -181,6 +205,7 @@ def call(name, *args, flops=0):
                 dev = a.dev
     if dev is None:
         dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    global CALL_COUNT
     lib = init(dev)
     if dev != torch.cuda.current_device():
         with torch.cuda.device(dev):
@@ -192,6 +217,7 @@ def call(name, *args, flops=0):
     if timed:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record(stream)
+    CALL_COUNT += 1
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise UnividHipError(f"{name} failed ({rc}): {lib.uv_last_error().decode()}")

@@ -20,9 +20,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-va
          "-ffp-contract=off"]
 
 
-# per-file additions. attn_pw4.hip: its slots are hand-placed scalar f32 operations beside MFMAs; SLP-packing them into v_pk_*_f32
-# costs issue cycles there (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
-FILE_FLAGS = {"attn_pw4.hip": ["-fno-slp-vectorize", "-Wno-inline-asm"]}
+# per-file additions (none in the product library since round 4). The diagnostic kernel tools/diag/attn_pw4.hip is built by
+# tools/diag/build_diag.py with DIAG_PW4_FLAGS: its slots are hand-placed scalar f32 operations beside MFMAs; SLP-packing them into
+# v_pk_*_f32 costs issue cycles there (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+FILE_FLAGS = {}
+DIAG_PW4_FLAGS = ["-fno-slp-vectorize", "-Wno-inline-asm"]
 
 
 def _hipcc():

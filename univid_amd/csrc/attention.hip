@@ -45,8 +45,6 @@ __device__ unsigned long long* uv_attn_tl;
 #define UV_TL_HW(id) do {} while (0)
 #endif
 
-#define UV_ATTN_LONG_DEFAULT_PW4 false
-
 typedef __attribute__((address_space(3))) void lds_void_a;
 
 // D = head_dim (128 for TI2V-5B; 64 for the reference's CPU-runnable tiny config and the SigLIP2 ranker).
@@ -984,18 +982,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // ---- kernel selection: the ONE place that decides which kernel serves a call ------------------------------------------------
-enum AttnKernel { ATT_FWD12 = 0, ATT_FWD3 = 1, ATT_FWD_D128 = 2, ATT_FWD_D64 = 3, ATT_PW4 = 4 };
+enum AttnKernel { ATT_FWD12 = 0, ATT_FWD3 = 1, ATT_FWD_D128 = 2, ATT_FWD_D64 = 3 };
 static const char* const kAttnKernelName[] = {"flash_attn_fwd12_kernel", "flash_attn_fwd3_kernel", "flash_attn_fwd_kernel<128>",
-                                              "flash_attn_fwd_kernel<64>", "flash_attn_pw4_kernel"};
-
-// Which kernel serves long key sequences: UV_ATTN_LONG=fwd12 | pw4 in the environment (read per call; developer A/B knob for
-// tools/attn_bench.py - both kernels produce bit-identical output), default below.
-static bool attn_long_pw4() {
-    const char* e = getenv("UV_ATTN_LONG");
-    if (e && e[0] == 'f') return false;
-    if (e && e[0] == 'p') return true;
-    return UV_ATTN_LONG_DEFAULT_PW4;
-}
+                                              "flash_attn_fwd_kernel<64>"};
 
 static AttnKernel attn_select(int Lk, int head_dim, long ldk, long ldvt, bool f16) {
     if (head_dim != 128) return ATT_FWD_D64;
@@ -1005,7 +994,7 @@ static AttnKernel attn_select(int Lk, int head_dim, long ldk, long ldvt, bool f1
     // traffic; -2.8 % on the self-attention launches); short ones (cross-attention, Lk = 512: prologue and last round weigh
     // more) keep the 4-wave workgroups (the 12-wave form is 24 % slower there)
     if (Lk < 2048) return ATT_FWD3;
-    return attn_long_pw4() ? ATT_PW4 : ATT_FWD12;
+    return ATT_FWD12;
 }
 
 // Cut of a (sample, head)'s NWU = ceil(Lq / 32) query units into n12 blocks of 12 units followed by n8 blocks of 8 units for
@@ -1082,13 +1071,15 @@ static int attn_entry(const char* name, const void* q, long ldq, const void* k, 
             {
                 int n12 = 0, n8 = 0;
                 attn12_cut(Lq, H * batch, &n12, &n8);
+                if (const int force = uv_option(UV_OPT_ATTN_CUT); force > 0) {       // A/B tools: n8 = force - 1 eight-unit blocks per head
+                    const int nwu = (Lq + UV_ATT_QW - 1) / UV_ATT_QW, rest = nwu - 8 * (force - 1);
+                    n8 = force - 1;
+                    n12 = rest > 0 ? (rest + 11) / 12 : 0;
+                }
                 a.n12 = n12;
                 a.q_blocks = n12 + n8;
             }
             hipLaunchKernelGGL((flash_attn_fwd12_kernel<3, true>), dim3(a.q_blocks * H * batch), dim3(768), 0, st, a);
-            break;
-        case ATT_PW4:
-            uv_launch_attn_pw4(a, st);
             break;
         case ATT_FWD3:
             a.q_blocks = (Lq + 127) / 128;

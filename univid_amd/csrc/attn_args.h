@@ -1,4 +1,4 @@
-// Argument block and shared constants of the flash-attention kernels (attention.hip, attn_pw4.hip).
+// Argument block and shared constants of the flash-attention kernels (attention.hip; tools/diag/attn_pw4.hip).
 #pragma once
 #include "common.h"
 
@@ -20,6 +20,3 @@ struct AttnArgs {
 __device__ __forceinline__ int perm23(int i) {  // swap bits 2 and 3
     return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
-
-// attn_pw4.hip: the 4-wave, one-wave-per-SIMD, 64-queries-per-wave kernel for long key sequences (head_dim 128, bf16)
-int uv_launch_attn_pw4(const AttnArgs& a, hipStream_t st);

@@ -4,6 +4,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -24,6 +25,31 @@ extern "C" int uv_version(void) { return 200; }  // 0.2.0
 #define UV_BUILD_ID "unstamped"
 #endif
 extern "C" const char* uv_build_id(void) { return UV_BUILD_ID; }
+
+// ---- developer options: explicit, process-wide, lock-free (see common.h) ----
+static std::atomic<int> g_opt[UV_OPT_COUNT] = {{-1}, {0}, {0}};
+static const int kOptDefault[UV_OPT_COUNT] = {-1, 0, 0};
+int uv_option(int key) { return g_opt[key].load(std::memory_order_relaxed); }
+
+extern "C" int uv_set_option(int key, int value) {
+    UV_CHECK_ARG(key >= 0 && key < UV_OPT_COUNT, "uv_set_option: unknown key %d", key);
+    if (key == UV_OPT_CONV_HALO) UV_CHECK_ARG(value >= -1 && value <= 1, "uv_set_option(UV_OPT_CONV_HALO): value %d not in {-1, 0, 1}", value);
+    if (key == UV_OPT_GEMM_GM) UV_CHECK_ARG(value >= 0 && value <= 64, "uv_set_option(UV_OPT_GEMM_GM): value %d not in 0..64", value);
+    if (key == UV_OPT_ATTN_CUT) UV_CHECK_ARG(value >= 0 && value <= 4096, "uv_set_option(UV_OPT_ATTN_CUT): value %d not in 0..4096", value);
+    g_opt[key].store(value, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int uv_get_option(int key, int* value) {
+    UV_CHECK_ARG(key >= 0 && key < UV_OPT_COUNT && value, "uv_get_option: unknown key %d or null result pointer", key);
+    *value = uv_option(key);
+    return 0;
+}
+
+extern "C" int uv_reset_options(void) {
+    for (int i = 0; i < UV_OPT_COUNT; ++i) g_opt[i].store(kOptDefault[i], std::memory_order_relaxed);
+    return 0;
+}
 
 const float* uv_zero_page();
 

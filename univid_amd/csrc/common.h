@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 typedef uint16_t bf16_t;  // raw bf16 bits in HBM
 
@@ -24,15 +25,24 @@ static inline int uv_cur_dev() {
     (void)hipGetDevice(&d);
     return (unsigned)d < UV_MAX_DEV ? d : 0;
 }
+// One-time, per-device host setup (hipFuncSetAttribute of a kernel's dynamic LDS size): one std::once_flag per device at the call
+// site, so two host threads (one per GPU; ctypes releases the GIL) never race on a plain flag.
+#define UV_ONCE_PER_DEVICE(...)                                                      \
+    do {                                                                             \
+        static std::once_flag uv_once_[UV_MAX_DEV];                                  \
+        std::call_once(uv_once_[uv_cur_dev()], [&] { __VA_ARGS__; });                \
+    } while (0)
 // Compute units of the current device (256 on MI355X); launch-geometry decisions (whole rounds of workgroups) use it.
 static inline int uv_num_cus() {
     static int cus[UV_MAX_DEV];
+    static std::once_flag once[UV_MAX_DEV];
     const int dev = uv_cur_dev();
-    int& n = cus[dev];
-    if (!n) {
+    std::call_once(once[dev], [&] {
+        int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    }
-    return n;
+        cus[dev] = n;
+    });
+    return cus[dev];
 }
 
 // f32 -> bf16, round-to-nearest-even (same rounding torch's .to(bfloat16) uses).
@@ -101,6 +111,15 @@ __device__ __forceinline__ float gelu_tanh_f32(float x) {
 }
 
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
+
+// Developer options (include/univid_hip.h: uv_set_option). Process-wide relaxed atomics: set explicitly through the C ABI, never
+// read from the environment (getenv racing with a putenv on another host thread is undefined behaviour, and a stray variable would
+// silently switch a summation order).
+#define UV_OPT_CONV_HALO 0     // -1 automatic (default), 0 never the LDS-halo convolution kernel, 1 whenever the geometry fits
+#define UV_OPT_GEMM_GM 1       // 0 automatic (default), > 0: tile-walk group height of the persistent GEMM
+#define UV_OPT_ATTN_CUT 2      // 0 automatic (default); v > 0: flash_attn_fwd12_kernel cuts every head with n8 = v - 1 eight-unit blocks (A/B tools)
+#define UV_OPT_COUNT 3
+int uv_option(int key);
 
 // error plumbing shared by the extern "C" entry points
 extern "C" const char* uv_last_error(void);

@@ -342,12 +342,7 @@ static void launch_conv(ConvArgs& a, hipStream_t stream) {
     a.tiles_n = (a.Cout + BN - 1) / BN;
     auto kern = conv3d_f32_kernel<BM, BN, WM, WN, PREC>;
     const size_t lds = 2 * (BM * 128 + BN * (PREC == 3 ? 192 : 128));
-    static bool attr_set[UV_MAX_DEV];
-    bool& attr = attr_set[uv_cur_dev()];
-    if (!attr) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, stream, a);
 }
 

@@ -287,8 +287,8 @@ __global__ __launch_bounds__(TW * 16) __attribute__((amdgpu_waves_per_eu(WBUF ==
 
 // Which convolutions take the halo kernel: 3x3 spatial taps, stride 1, padding 1 (plain or behind the 2x upsampling), no interleave, whole 32-channel input
 // blocks (all callers pad), whole 128-wide output-channel tiles, and enough tiles per frame to fill the chip at four frames per pass.
-// UV_CONV_HALO in the environment (developer A/B knob and test hook, read per call): "0" = never, "1" = whenever the geometry fits
-// (also launches too small to fill the chip, which the tests use), unset = automatic (both arithmetics).
+// uv_set_option(UV_OPT_CONV_HALO, v) (developer A/B switch and test hook; never the environment): 0 = never, 1 = whenever the geometry
+// fits (also launches too small to fill the chip, which the tests use), -1 = automatic (default; both arithmetics).
 // output-channel tile of the halo kernel for this convolution (0: none fits): whole 128-wide tiles, or - exact f32 - whole 160-wide ones
 static int uv_conv3d_halo_bn(const ConvArgs& a, int prec) {
     if (a.Cout % 128 == 0) return 128;
@@ -297,8 +297,8 @@ static int uv_conv3d_halo_bn(const ConvArgs& a, int prec) {
 }
 
 bool uv_conv3d_halo_eligible(const ConvArgs& a, int prec) {
-    const char* e = getenv("UV_CONV_HALO");
-    if (e && e[0] == '0') return false;
+    const int force = uv_option(UV_OPT_CONV_HALO);
+    if (force == 0) return false;
     if (!(prec == 0 || prec == 3)) return false;
     if (a.kh != 3 || a.kw != 3 || (a.kt != 3 && a.kt != 1)) return false;
     if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.interleave) return false;
@@ -310,23 +310,21 @@ bool uv_conv3d_halo_eligible(const ConvArgs& a, int prec) {
     // (exact f32: 8 x 16 patches on 4-wave workgroups, two per CU - 6.28 s against 6.43 s per 49 x 720 x 1280 decode on the gather kernel,
     // same process, interleaved; the 8-wave form of round 3's first version lost to it, 6.49 s, with one workgroup per CU)
     const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + (prec == 3 ? 31 : 15)) / (prec == 3 ? 32 : 16)) * (a.Cout / bn);
-    return (e && e[0] == '1') || 4 * tiles >= (prec == 3 ? 1 : 2) * uv_num_cus();
+    return force == 1 || 4 * tiles >= (prec == 3 ? 1 : 2) * uv_num_cus();
 }
 
 int uv_launch_conv3d_halo(ConvArgs& a, int prec, hipStream_t stream) {
     const int bn = uv_conv3d_halo_bn(a, prec);
     a.tiles_n = a.Cout / bn;
-    static bool attr_set[UV_MAX_DEV][3];
-    bool& attr = attr_set[uv_cur_dev()][prec == 3 ? 1 : bn == 160 ? 2 : 0];
     if (prec == 3) {
         a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
         const size_t lds = 3 * 344 * 64 + 2 * 128 * 192;
-        if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)conv3d_halo_kernel<3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((conv3d_halo_kernel<3, 32>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
     } else if (bn == 160) {
         a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 15) / 16);
         const size_t lds = 184 * 128 + 2 * 160 * 128;          // 63 KiB: two workgroups per CU
-        if (!attr) hipFuncSetAttribute((const void*)conv3d_halo_kernel<0, 16, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)conv3d_halo_kernel<0, 16, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((conv3d_halo_kernel<0, 16, 160>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
     } else {
         a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 15) / 16);
@@ -335,6 +333,5 @@ int uv_launch_conv3d_halo(ConvArgs& a, int prec, hipStream_t stream) {
         const size_t lds = 184 * 128 + 128 * 128;
         hipLaunchKernelGGL((conv3d_halo_kernel<0, 16, 128, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
     }
-    attr = true;
     return 0;
 }

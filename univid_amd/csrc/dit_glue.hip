@@ -303,11 +303,16 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsRopeArgs p) {
                             split_factor(*(const f64x2*)(p.freqs + ((long)pos * half + ci) * 2), rh, rl, ih, il);
                         }
                         // (a + i b)(cr + i ci) of the reference's complex128 product, then .float(): evaluated in f32 with the factor
-                        // tails carried, innermost (smallest) terms first. a and b are f32 exactly; the two outer fused multiply-adds
-                        // round to f32 once each, so the result is within 1 f32 ulp of float(fp64 product) - the bf16 rounding that
-                        // follows sees a different value only when the exact result lies within 2^-16 of a bf16 rounding boundary
-                        // (~1e-5 of the elements; was: four f64 multiplies + two f64 adds + four conversions per pair, a third of
-                        // the kernel's time).
+                        // tails carried, innermost (smallest) terms first. a and b are f32 exactly. Error bound (round-3 advisor): every
+                        // fused multiply-add rounds its running sum to f32, so the ABSOLUTE error of a component is <= 2^-24 (|a cr| + |b ci|)
+                        // (+ second-order terms) - NOT "1 f32 ulp of float(fp64 product)": under cancellation (a cr ~ b ci) that is many
+                        // ulps of the small result. For the bf16 rounding that follows what matters is the absolute error against the bf16
+                        // spacing of the OUTPUT, and the output's rms is that of the inputs (a unit rotation): the rounded value differs
+                        // from the reference's complex128 path only when the exact result lies within ~2^-16 relative to the pair's larger
+                        // element of a bf16 rounding boundary - measured 1.3e-5 of the elements (tests/manual/rope_ulp_stats.py; plain f32
+                        // factors without the tails: 1.9e-5; fp64 arithmetic: 1.0e-6, the sum-of-squares order alone), never more than one
+                        // bf16 ulp of the rotated pair's larger element, which is the test's gate (rare=(2e-5, 2 ulp)). Was: four f64
+                        // multiplies + two f64 adds + four conversions per pair.
                         const float a = y[2 * e], b = y[2 * e + 1];
                         y[2 * e] = __builtin_fmaf(a, rh, __builtin_fmaf(-b, ih, __builtin_fmaf(a, rl, -__fmul_rn(b, il))));
                         y[2 * e + 1] = __builtin_fmaf(a, ih, __builtin_fmaf(b, rh, __builtin_fmaf(a, il, __fmul_rn(b, rl))));

@@ -890,13 +890,7 @@ static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
 #define UV_LAUNCH8(E)                                                                              \
     case E: {                                                                                      \
         auto kern = gemm_bf16_8ph_kernel<E, VAR, F16>;                                               \
-        static bool attr_set[UV_MAX_DEV];                                                          \
-        bool& attr_done = attr_set[uv_cur_dev()];                                                  \
-        if (!attr_done) {                                                                          \
-            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                (int)lds);                                                         \
-            attr_done = true;                                                                      \
-        }                                                                                          \
+        UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                     \
         break;                                                                                     \
     }
@@ -927,7 +921,7 @@ static int launch_8ph_persist(const GemmArgs& a0, int epi, hipStream_t stream) {
     // height of the tile walk's column groups (same-process A/B on the DiT shapes, tools/gemm_gm_ab.py: N = K = 3072 325 -> 319 us at 8,
     // N = 14336 best at 4, K = 14336 1438 -> 1428 us at 2; the results do not depend on it)
     a.gm = (a.N <= 4096 && a.K <= 4096) ? 8 : (a.K >= 8192 ? 2 : 4);
-    if (const char* e = getenv("UV_GEMM_GM")) a.gm = atoi(e) > 0 ? atoi(e) : a.gm;    // developer A/B knob
+    if (const int gm = uv_option(UV_OPT_GEMM_GM); gm > 0) a.gm = gm;                  // developer A/B switch (uv_set_option)
     const int tiles = a.tiles_m * a.tiles_n;
     int wgs = uv_num_cus() & ~7;
     if (wgs > tiles) wgs = tiles & ~7;
@@ -937,13 +931,7 @@ static int launch_8ph_persist(const GemmArgs& a0, int epi, hipStream_t stream) {
 #define UV_LAUNCH8P(E)                                                                             \
     case E: {                                                                                      \
         auto kern = gemm_bf16_8ph_persist_kernel<E, F16>;                                          \
-        static bool attr_set[UV_MAX_DEV];                                                          \
-        bool& attr_done = attr_set[uv_cur_dev()];                                                  \
-        if (!attr_done) {                                                                          \
-            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                (int)lds);                                                         \
-            attr_done = true;                                                                      \
-        }                                                                                          \
+        UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                     \
         break;                                                                                     \
     }
@@ -973,13 +961,7 @@ static int launch_cfg(const GemmArgs& a0, int epi, hipStream_t stream) {
 #define UV_LAUNCH(E)                                                                               \
     case E: {                                                                                      \
         auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, E, NS, F16>;                                \
-        static bool attr_set[UV_MAX_DEV];                                                          \
-        bool& attr_done = attr_set[uv_cur_dev()];                                                  \
-        if (!attr_done) {                                                                          \
-            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                (int)lds);                                                         \
-            attr_done = true;                                                                      \
-        }                                                                                          \
+        UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                     \
         break;                                                                                     \
     }

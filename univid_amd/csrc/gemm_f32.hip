@@ -161,9 +161,7 @@ extern "C" int uv_gemm_f32_nt(const float* A, long lda, const float* W, long ldw
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     auto kern = gemm_f32_nt_kernel<BM, BN, 2, 2>;
     const size_t lds = 2 * (BM + BN) * 128;
-    static bool attr_set[UV_MAX_DEV];
-    bool& attr = attr_set[uv_cur_dev()];
-    if (!attr) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, (hipStream_t)stream, a);
     UV_CHECK_LAUNCH("uv_gemm_f32_nt");
     return 0;

@@ -264,8 +264,14 @@ class WanTI2V:
         if graph:
             # one captured graph per (latent shape, mode, contexts, prepared weights): generations that repeat them replay it
             _ensure_prepared(self.model)
-            key = (tuple(latent.shape), i2v, tuple((u.data_ptr(), tensor_version(u)) for u in list(context) + list(context_null)),
-                   self.model._prep_gen)
+            vers = tuple((u.data_ptr(), tensor_version(u)) for u in list(context) + list(context_null))
+            # A tensor created under torch.inference_mode() has no version counter (tensor_version == -1): an in-place refill of a
+            # preallocated prompt-embeds buffer between two generations is then invisible to the key, and a reused runner would replay
+            # the cross-attention K / V^T of the OLD prompt (round-3 advisor finding). Such contexts never reuse a runner across
+            # denoise calls: the key carries a per-call token, so the graph is recaptured (inside one call the loop owns its tensors).
+            self._denoise_calls = getattr(self, "_denoise_calls", 0) + 1
+            once = self._denoise_calls if any(v == -1 for _, v in vers) else 0
+            key = (tuple(latent.shape), i2v, vers, self.model._prep_gen, once)
             runner = self._runner if (self._runner is not None and self._runner.key == key and
                                       self._runner.gen == self.model._ctx_gen) else None
             if runner is None:
