@@ -243,11 +243,14 @@ def _vae_bound(precision, tflops):
     if precision == "fp32":
         return {"bound_tflops": PEAK_F32_MFMA_TFLOPS, "vs_bound": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "bound": "f32 MFMA peak"}
     n = 6 if precision == "bf16x6" else 3
+    pipe = "fp16" if precision == "f16x3" else "bf16"       # same dense peak
     return {"bound_tflops": round(PEAK_BF16_TFLOPS / n, 1), "vs_bound": round(tflops / (PEAK_BF16_TFLOPS / n), 4),
-            "bound": f"bf16 MFMA peak / {n} passes"}
+            "bound": f"{pipe} MFMA peak / {n} passes"}
 
 
 _VAE_DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (f32 accumulate)",
+              "f16x3": "f32-grade in 3 passes: the convolutions behind an RMS_norm take both operands as two IEEE fp16 pieces (22 significant bits; "
+                       "error vs fp64 = the f32 MFMA kernel's, accumulation-bound), products on the fp16 MFMA, f32 accumulate; the other convolutions as bf16x6",
               "bf16x6": "f32 operands, products on the bf16 MFMA by exact 3-way splitting (6 passes, error < 2^-26 per product), f32 accumulate"}
 
 
@@ -584,6 +587,8 @@ def main():
             out["vae_decode"], out["vae_encode"] = f32["decode"], f32["encode"]
             x6 = vae_metrics(device, "bf16x6")
             out["vae_decode_bf16x6"], out["vae_encode_bf16x6"] = x6["decode"], x6["encode"]
+            x3 = vae_metrics(device, "f16x3")
+            out["vae_decode_f16x3"], out["vae_encode_f16x3"] = x3["decode"], x3["encode"]
             out["vae_decode_bf16x3"] = vae_metrics(device, "bf16x3", encode=False)["decode"]
         if world == 1 and not args.no_vae and not args.layers and args.shape == "A":
             try:

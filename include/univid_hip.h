@@ -204,7 +204,20 @@ int uv_conv3d_bf16x3(const float* in, long ld_in, int Tin, int Hin, int Win, con
                      int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr, int in_split, void* stream);
 /* w [n] f32 (rows of K, K % 32 == 0) -> [n/32][32 hi | 32 lo] bf16 with hi = bf16(w), lo = bf16(w - hi) */
 int uv_split_weights_bf16x3(const float* w, void* out, long n, void* stream);
-/* y = x / max(||x||,1e-12) * sqrt(C) * gamma [-> SiLU] per pixel (RMS_norm + SiLU, vae2_2.py:45-59, 201-206) */
+/* The same convolution, f32-GRADE, in THREE fp16 MFMA passes ("f16x3"): both operands pre-split into two IEEE fp16 pieces (hi = fp16(x),
+ * lo = fp16(x - hi): x to 2^-22 relative), x*w ~ xh*wh + xh*wl + xl*wh on v_mfma_f32_16x16x32_f16, f32 accumulate. Against an fp64
+ * convolution it is as close as uv_conv3d_f32: at K = 27 C both are dominated by the f32 accumulation error (tests: test_conv3d_f16x3_is_f32_grade).
+ * `in` holds PRE-SPLIT activations ([C/32][32 hi | 32 lo] fp16 per pixel = the bytes of an f32 pixel; written by uv_vae_rms_silu(split_out=2);
+ * |x| < 65 504: an RMS-normalised row is bounded by sqrt(C) max|gamma|, which the caller checks); w_split = uv_split_weights_f16x3(w, w_scale)
+ * with w_scale a power of two (max|w| * w_scale in [2^13, 2^14) keeps the lo pieces normal); out = acc / w_scale + bias (+ resid), f32.
+ * Replaces the same reference lines as uv_conv3d_f32 for the convolutions that follow an RMS_norm (ResidualBlock, heads: vae2_2.py:193-235). */
+int uv_conv3d_f16x3(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w_split, const float* bias, float* out, long ldo,
+                    int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw, int t_off, int ph,
+                    int pw, int up, int interleave, const float* resid, long ldr, float w_scale, void* stream);
+/* w [n] f32 (rows of K, K % 32 == 0) -> [n/32][32 hi | 32 lo] IEEE fp16 with hi = fp16(w * scale), lo = fp16(w * scale - hi); scale = 2^s */
+int uv_split_weights_f16x3(const float* w, void* out, long n, float scale, void* stream);
+/* y = x / max(||x||,1e-12) * sqrt(C) * gamma [-> SiLU] per pixel (RMS_norm + SiLU, vae2_2.py:45-59, 201-206).
+ * split_out: 0 = f32 rows; 1 = [C/32][32 hi | 32 lo] bf16 pieces (uv_conv3d_bf16x3 in_split); 2 = the same layout in IEEE fp16 (uv_conv3d_f16x3). */
 int uv_vae_rms_silu(const float* in, long ld_in, const float* gamma, float* out, long ld_out, long P, int C, int do_silu,
                     int split_out, void* stream);
 /* in-place row softmax of x*scale (AttentionBlock's SDPA, vae2_2.py:267-271) */

@@ -1327,7 +1327,7 @@ def test_vae_heavy_tailed_input_stress_vs_oracle():
         ref_d, ref_e = wan_vae.vae_decode(ora, [z])[0], wan_vae.vae_encode(ora, [vid])[0]
         tru_d = wan_vae.vae_decode(ora64, [z.double()], scale=wan_vae.scale_tensors(torch.float64))[0]
         tru_e = wan_vae.vae_encode(ora64, [vid.double()], scale=wan_vae.scale_tensors(torch.float64))[0]
-    for prec in ("fp32", "bf16x6"):
+    for prec in ("fp32", "bf16x6", "f16x3"):
         vae = vae0 if prec == "fp32" else Wan2_2_VAE(c_dim=cfg["dim"], dec_dim=cfg["dec_dim"], device=DEV, seed=3, precision=prec)
         with torch.no_grad():
             got_d, got_e = vae.decode([z.to(DEV)])[0].cpu(), vae.encode([vid.to(DEV)])[0].cpu()
@@ -1839,6 +1839,39 @@ def test_vae_bf16x6_precision_mode_vs_golden():
         assert e6 < 2.0 * e0 + 1e-6, (i, e6, e0)
 
 
+def test_vae_f16x3_precision_mode_vs_golden():
+    """precision='f16x3' (f32-grade in three fp16 MFMA passes for the convolutions behind an RMS_norm, bf16x6 for the others): the
+    small-VAE goldens at the same tolerance as fp32, as close to the reference output as the exact-f32 mode is, and the range guard: a
+    norm whose sqrt(C) max|gamma| bound exceeds fp16's range keeps its convolution on bf16x6 (finite output, same tolerance)."""
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    g = load_golden("vae_small")
+    vae = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=g["seed"], precision="f16x3")
+    exact = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=g["seed"])
+    for i in range(3):
+        with torch.no_grad():
+            v, z = vae.decode([g[f"dec_in_{i}"].to(DEV)])[0], vae.encode([g[f"enc_in_{i}"].to(DEV)])[0]
+            v0, z0 = exact.decode([g[f"dec_in_{i}"].to(DEV)])[0], exact.encode([g[f"enc_in_{i}"].to(DEV)])[0]
+        assert_f32_close(v, g[f"dec_out_{i}"], name=f"f16x3 decode {i}")
+        assert_f32_close(z, g[f"enc_out_{i}"], name=f"f16x3 encode {i}")
+        e3, e0 = (v.cpu() - g[f"dec_out_{i}"]).abs().max().item(), (v0.cpu() - g[f"dec_out_{i}"]).abs().max().item()
+        assert e3 < 2.0 * e0 + 1e-6, (i, e3, e0)
+    eng = vae.model._eng()
+    used = sorted(set(eng._fmt.values()))
+    assert used == [2], f"every RMS_norm of the small VAE is inside fp16's range: {used}"
+    # a huge gamma (x 1e5, with the following convolution's weights scaled back): out of fp16's range -> that convolution runs as bf16x6
+    big = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=g["seed"], precision="f16x3")
+    blk = big.model.decoder.middle[0]
+    with torch.no_grad():
+        blk.residual[0].gamma.mul_(1e5)
+        blk.residual[2].weight.mul_(1e-5)
+    big.model.invalidate()
+    with torch.no_grad():
+        vb = big.decode([g["dec_in_1"].to(DEV)])[0]
+    assert 0 in big.model._eng()._fmt.values()
+    assert torch.isfinite(vb).all()
+    assert_f32_close(vb, g["dec_out_1"], rtol=1e-3, atol=2e-4, name="f16x3 with one norm outside fp16's range")
+
+
 def test_vae_full_width_vs_oracle():
     """The production VAE widths (encoder 160..640, decoder 1024..256 channels, z = 48) on a small clip, fp32 mode and
     bf16x3 mode, against the CPU oracle run here."""
@@ -1854,7 +1887,7 @@ def test_vae_full_width_vs_oracle():
     with torch.no_grad():
         ref_dec = wan_vae.vae_decode(ora, [z])[0]
         ref_enc = wan_vae.vae_encode(ora, [vid])[0]
-    for prec in ("fp32", "bf16x6", "bf16x3"):
+    for prec in ("fp32", "bf16x6", "f16x3", "bf16x3"):
         vae = Wan2_2_VAE(device=DEV, precision=prec)
         vae.model.load_state_dict(sd)
         with torch.no_grad():
@@ -1862,7 +1895,7 @@ def test_vae_full_width_vs_oracle():
             assert_f32_close(vae.encode([vid.to(DEV)])[0], ref_enc, name=f"full-width encode {prec}")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "f16x3"])
 def test_vae_config4_full_resolution_frame_vs_cpu_oracle(prec):
     """BASELINE config 4 at its REAL spatial size, every element value-checked against the pinned CPU oracle: the full-width decoder
     on one latent frame [48, 1, 45, 80] -> one 720 x 1280 RGB frame (every decoder layer at its full 90x160 .. 720x1280 geometry: 57 600 /
@@ -1930,10 +1963,34 @@ def _split6(wp):
     return out
 
 
-@pytest.mark.parametrize("entry", ["uv_conv3d_f32", "uv_conv3d_bf16x6"])
+def _split_f16_weights(wp):
+    """uv_split_weights_f16x3 of a [Cout, K] f32 weight matrix with the engine's scale rule (max |w| * scale in [2^13, 2^14)) + a check
+    that hi + lo reproduces w * scale to 2^-22 relative (of the row's largest weights: tiny weights have subnormal lo pieces)."""
+    from univid_amd import _lib
+    mx = float(wp.abs().max())
+    scale = 2.0 ** (13 - math.floor(math.log2(mx)))
+    out = torch.empty(wp.numel() * 2, dtype=torch.float16, device=wp.device)
+    _lib.call("uv_split_weights_f16x3", _lib.ptr(wp), _lib.ptr(out), wp.numel(), scale, _lib.stream_ptr())
+    pl = out.view(wp.shape[0], -1, 2, 32).double()
+    back = (pl[:, :, 0] + pl[:, :, 1]) / scale
+    assert ((back - wp.view(wp.shape[0], -1, 32).double()).abs() <= 2.0 ** -22 * wp.abs().double().view(wp.shape[0], -1, 32) + 2.0 ** -25 / scale).all(), "w != (hi + lo) / scale"
+    return out, scale
+
+
+def _split_f16_acts(x_cl):
+    """[.., C] f32 (C % 32 == 0) -> the same bytes holding [C/32][32 hi | 32 lo] IEEE fp16 per pixel: what uv_vae_rms_silu(split_out=2) writes."""
+    hi = x_cl.half()
+    lo = (x_cl - hi.float()).half()
+    C = x_cl.shape[-1]
+    both = torch.stack((hi.view(*x_cl.shape[:-1], C // 32, 32), lo.view(*x_cl.shape[:-1], C // 32, 32)), dim=-2)   # [.., C/32, 2, 32]
+    return both.reshape(*x_cl.shape[:-1], 2 * C).contiguous().view(torch.float32)                                 # [.., C] f32-sized
+
+
+@pytest.mark.parametrize("entry", ["uv_conv3d_f32", "uv_conv3d_bf16x6", "uv_conv3d_f16x3"])
 def test_conv3d_kernel_geometries(entry):
-    """Every convolution geometry the VAE uses, against F.conv3d / F.conv2d: the exact-f32 MFMA kernel and the same kernel with
-    the products on the bf16 matrix pipe by exact three-way operand splitting (same memory formats, same tolerance)."""
+    """Every convolution geometry the VAE uses, against F.conv3d / F.conv2d: the exact-f32 MFMA kernel, the same kernel with
+    the products on the bf16 matrix pipe by exact three-way operand splitting (same memory formats, same tolerance), and the f32-grade
+    three-pass fp16 form on pre-split operands (uv_conv3d_f16x3; same tolerance)."""
     import torch.nn.functional as F
     from univid_amd import _lib
     g = torch.Generator().manual_seed(4)
@@ -1942,13 +1999,18 @@ def test_conv3d_kernel_geometries(entry):
         T, H, W, C = x_cl.shape
         co, ci, kt, kh, kw_ = w.shape
         wp = w.permute(0, 2, 3, 4, 1).reshape(co, -1).contiguous().to(DEV)
+        extra = ()
         if entry == "uv_conv3d_bf16x6":
             wp = _split6(wp)
+        elif entry == "uv_conv3d_f16x3":        # both operands as two fp16 pieces (activations pre-split, as uv_vae_rms_silu writes them)
+            wp, scale = _split_f16_weights(wp)
+            x_cl = _split_f16_acts(x_cl)
+            extra = (scale,)
         inter = kw.get("interleave", 0)
         out = torch.empty(Tout * (2 if inter else 1), Hout, Wout, co // (2 if inter else 1), device=DEV)
         _lib.call(entry, _lib.ptr(x_cl), C, T, H, W, _lib.ptr(wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), out.shape[-1],
                   Tout, Hout, Wout, C, co, kt, kh, kw_, kw.get("st", 1), kw.get("sh", 1), kw.get("sw", 1), kw.get("t_off", 0),
-                  kw.get("ph", 0), kw.get("pw", 0), kw.get("up", 0), inter, None, 0, _lib.stream_ptr())
+                  kw.get("ph", 0), kw.get("pw", 0), kw.get("up", 0), inter, None, 0, *extra, _lib.stream_ptr())
         return out.cpu()
 
     x = torch.randn(1, 64, 5, 6, 7, generator=g)
@@ -2038,7 +2100,10 @@ def test_conv3d_bf16x6_is_f32_grade():
     """uv_conv3d_bf16x6 (three bf16 planes per f32 operand, the six product terms with i + j <= 2, f32 accumulate) against an fp64
     convolution of the same f32 operands, next to the exact-f32 MFMA kernel: at the decoder's channel counts (K = 27 C up to 27 648)
     its error must not exceed the f32 kernel's (measured: 0.87-0.89 x) - it is the f32 arithmetic on another pipe, not a narrower
-    one (the 2-way split bf16x3 drops the lo.lo term and is ~20 x further from fp64)."""
+    one (the 2-way split bf16x3 drops the lo.lo term and is ~20 x further from fp64).
+    uv_conv3d_f16x3 (two IEEE fp16 pieces per operand = 22 significant bits, three fp16 MFMA passes) is measured beside them: its
+    operands ARE narrower than f32 (2^-22 against 2^-24 relative), but at these K the error of every one of these kernels against fp64 is
+    the f32 ACCUMULATION's (~1e-6), which the 22-bit operands raise by a few per cent: gate <= 1.25 x the exact-f32 kernel's error."""
     import torch.nn.functional as F
     from univid_amd import _lib
     g = torch.Generator().manual_seed(0)
@@ -2052,17 +2117,25 @@ def test_conv3d_bf16x6_is_f32_grade():
         x_cl = x[0].permute(1, 2, 3, 0).contiguous().to(DEV)
         wp = w.permute(0, 2, 3, 4, 1).reshape(co, -1).contiguous().to(DEV)
         err = {}
-        for name in ("uv_conv3d_f32", "uv_conv3d_bf16x6"):
+        for name in ("uv_conv3d_f32", "uv_conv3d_bf16x6", "uv_conv3d_f16x3"):
             out = torch.empty(T, H, W, co, device=DEV)
-            _lib.call(name, _lib.ptr(x_cl), C, T + 2, H, W, _lib.ptr(_split6(wp) if name.endswith("x6") else wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), co, T, H, W, C, co, 3, 3, 3,
-                      1, 1, 1, 0, 1, 1, 0, 0, None, 0, _lib.stream_ptr())
+            src, wt, extra = x_cl, wp, ()
+            if name.endswith("x6"):
+                wt = _split6(wp)
+            elif name.endswith("f16x3"):
+                wt, scale = _split_f16_weights(wp)
+                src, extra = _split_f16_acts(x_cl), (scale,)
+            _lib.call(name, _lib.ptr(src), C, T + 2, H, W, _lib.ptr(wt), _lib.ptr(b.to(DEV)), _lib.ptr(out), co, T, H, W, C, co, 3, 3, 3,
+                      1, 1, 1, 0, 1, 1, 0, 0, None, 0, *extra, _lib.stream_ptr())
             d = out.cpu().double() - ref
             err[name] = float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
         meas[f"C{C}_f32_mfma_rel_rms_vs_fp64"] = err["uv_conv3d_f32"]
         meas[f"C{C}_bf16x6_rel_rms_vs_fp64"] = err["uv_conv3d_bf16x6"]
+        meas[f"C{C}_f16x3_rel_rms_vs_fp64"] = err["uv_conv3d_f16x3"]
         assert err["uv_conv3d_bf16x6"] <= 1.05 * err["uv_conv3d_f32"], (C, err)
         assert err["uv_conv3d_bf16x6"] < 5e-6
-    record_margin("conv3d 3x3x3: error against fp64 (exact-f32 MFMA vs bf16x6)", **meas)
+        assert err["uv_conv3d_f16x3"] <= 1.25 * err["uv_conv3d_f32"], (C, err)
+    record_margin("conv3d 3x3x3: error against fp64 (exact-f32 MFMA vs bf16x6 vs f16x3)", **meas)
 
 
 # ---------------------------------------------------------------------------------------------------------------

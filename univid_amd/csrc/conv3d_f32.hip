@@ -20,6 +20,7 @@
 // a kernel tap reads.
 #include "conv_args.h"
 #include <stdlib.h>
+#include <math.h>
 
 typedef __attribute__((address_space(3))) void lds_void_c;
 
@@ -31,6 +32,17 @@ typedef __attribute__((address_space(3))) void lds_void_c;
 //         is shared); activations stay f32 in HBM/LDS and are split in registers.
 // PREC 2: bf16x3 with the ACTIVATIONS pre-split too (the producer, uv_vae_rms_silu, writes [C/32][32 hi | 32 lo] bf16 into
 //         the input ring: same bytes per pixel as f32): no conversion work in the MFMA loop at all.
+// PREC 4: "f16x3", f32-GRADE on HALF the passes of PREC 3: both operands pre-split into TWO IEEE fp16 pieces (hi = fp16(x), lo =
+//         fp16(x - hi): 11 + 11 significand bits and a sign = x to 2^-22 relative, worst case; same memory formats as PREC 2 with fp16 in
+//         place of bf16), x*w ~ xh*wh + xh*wl + xl*wh on the fp16 MFMA (v_mfma_f32_16x16x32_f16), f32 accumulate. The dropped xl*wl is
+//         2^-22 |x w|. Against an fp64 convolution the result is as close as the exact-f32 MFMA kernel's, because at K = 27 C both are
+//         dominated by the f32 ACCUMULATION error (1.4e-6 .. 2.8e-6 relative rms at K = 6 912 .. 27 648; the 22-bit operands add
+//         ~1.5e-7): test_conv3d_f16x3_is_f32_grade. fp16's range is what the caller must respect: the WEIGHTS are pre-scaled by a power
+//         of two (uv_split_weights_f16x3: max |w| * scale in [2^13, 2^14), so that the lo pieces of all but the smallest weights are
+//         normal fp16 numbers; undone exactly in the epilogue: out = acc * out_scale + bias), the ACTIVATIONS are taken as they are
+//         and must stay below 65 504 in magnitude - uv_vae_rms_silu(split_out = 2) writes them, and an RMS-normalised row is bounded by
+//         sqrt(C) max|gamma| (the host checks that bound per convolution and keeps PREC 3 where it does not hold). Activation lo pieces
+//         of |x| < 2^-3 are subnormal fp16: an ABSOLUTE error <= 2^-25 there, i.e. below f32's own rounding of the row's O(1) elements.
 // PREC 3: "bf16x6", f32-GRADE: every f32 operand is three bf16 planes (x = x0 + x1 + x2 exactly) and the product keeps the six
 //         terms with i + j <= 2 (error < 2^-26 |x w|, under f32's own rounding), f32 accumulate. Activations f32 in HBM/LDS, split in
 //         registers; weights pre-split on the host into [Cout][K/32][32 p0 | 32 p1 | 32 p2] bf16 and staged as three plane sub-tiles.
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
             bf16x8 ah[TM], al[TM], wh[TN], wl[TN];
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
-                if (PREC == 2) {
+                if (PREC == 2 || PREC == 4) {
                     ah[j] = *(const bf16x8*)(base + a_off[j] + ((fq ^ a_key[j]) << 4));
                     al[j] = *(const bf16x8*)(base + a_off[j] + (((4 + fq) ^ a_key[j]) << 4));
                     continue;
@@ -292,9 +304,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ah[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], al[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ah[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_16x16x32<PREC == 4>(wl[i], ah[j], acc[i][j]);
+                    acc[i][j] = mfma_16x16x32<PREC == 4>(wh[i], al[j], acc[i][j]);
+                    acc[i][j] = mfma_16x16x32<PREC == 4>(wh[i], ah[j], acc[i][j]);
                 }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -312,6 +324,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
             const int n = n0 + wn * (BN / WN) + i * 16 + 4 * fq;
             if (n >= p.Cout) continue;
             f32x4 v = acc[i][j];
+            if constexpr (PREC == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;        // exact: a power of two
+            }
             if (p.bias) {
                 const f32x4 b = *(const f32x4*)(p.bias + n);
 #pragma unroll
@@ -349,7 +365,7 @@ static void launch_conv(ConvArgs& a, hipStream_t stream) {
 static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w, const float* bias, float* out,
                        long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st, int sh,
                        int sw, int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr, int prec,
-                       void* stream) {
+                       void* stream, float out_scale = 1.0f) {
     UV_CHECK_ARG(in && w && out, "uv_conv3d: null pointer");
     UV_CHECK_ARG(Cin % 32 == 0, "uv_conv3d: Cin=%d must be a multiple of 32 (pad channels with zeros)", Cin);
     UV_CHECK_ARG(Cout % 4 == 0, "uv_conv3d: Cout=%d must be a multiple of 4", Cout);
@@ -366,6 +382,7 @@ static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, c
     a.Cin = Cin; a.Cout = Cout; a.kt = kt; a.kh = kh; a.kw = kw; a.st = st; a.sh = sh; a.sw = sw;
     a.t_off = t_off; a.ph = ph; a.pw = pw; a.up = up; a.interleave = interleave;
     a.M = Tout * Hout * Wout;
+    a.out_scale = out_scale;
     hipStream_t s = (hipStream_t)stream;
     // the large 3x3(x3) stride-1 convolutions (ResidualBlocks): LDS-halo kernel (conv3d_halo.hip), exact f32 and bf16x6
     if (uv_conv3d_halo_eligible(a, prec)) {
@@ -391,6 +408,11 @@ static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, c
         // 160-wide tiles carry 30 KiB of weight planes per stage: 64 rows keep two workgroups per CU (2 x 76 KiB of LDS)
         else if (Cout % 160 == 0 && Cout % 128 != 0) launch_conv<64, 160, 2, 2, 3>(a, s);
         else launch_conv<128, 128, 2, 2, 3>(a, s);
+    } else if (prec == 4) {
+        if (Cout <= 16) launch_conv<256, 16, 4, 1, 4>(a, s);
+        else if (Cout >= 256 && t256 >= 256) launch_conv<256, 256, 4, 4, 4>(a, s);
+        else if (t128 >= 256) launch_conv<256, 128, 4, 2, 4>(a, s);
+        else launch_conv<128, 128, 2, 2, 4>(a, s);
     } else if (prec == 1) {
         if (Cout >= 256 && t256 >= 256) launch_conv<256, 256, 4, 4, 1>(a, s);
         else if (t128 >= 256) launch_conv<256, 128, 4, 2, 1>(a, s);
@@ -444,6 +466,42 @@ extern "C" int uv_split_weights_bf16x6(const float* w, void* out, long n, void* 
     hipLaunchKernelGGL(split_weights6_kernel, dim3((unsigned)min((n + 255) / 256, (long)4096)), dim3(256), 0, (hipStream_t)stream, w,
                        (bf16_t*)out, n);
     UV_CHECK_LAUNCH("uv_split_weights_bf16x6");
+    return 0;
+}
+
+// Same convolution, f32-grade, in THREE fp16 MFMA passes (PREC 4 above). `in` holds PRE-SPLIT activations ([C/32][32 hi | 32 lo] IEEE fp16 per
+// pixel, written by uv_vae_rms_silu with split_out = 2; ld_in counted in f32-sized elements = channels; |x| < 65 504), w_split = the
+// weights split by uv_split_weights_f16x3 with the power-of-two `w_scale`; out = acc / w_scale + bias (+ residual), f32.
+extern "C" int uv_conv3d_f16x3(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w_split, const float* bias,
+                               float* out, long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st,
+                               int sh, int sw, int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr,
+                               float w_scale, void* stream) {
+    int ex = 0;
+    UV_CHECK_ARG(w_scale > 0.f && frexpf(w_scale, &ex) == 0.5f, "uv_conv3d_f16x3: w_scale=%g must be a power of two", (double)w_scale);
+    return conv_common(in, ld_in, Tin, Hin, Win, w_split, bias, out, ldo, Tout, Hout, Wout, Cin, Cout, kt, kh, kw, st, sh, sw, t_off,
+                       ph, pw, up, interleave, resid, ldr, 4, stream, 1.0f / w_scale);
+}
+
+// w [rows][K] f32 (K % 32 == 0) -> [rows][K/32][32 hi | 32 lo] IEEE fp16 with hi = fp16(w * scale), lo = fp16(w * scale - hi); scale is a
+// power of two chosen by the caller so that max |w| * scale < 65 504 (round to nearest; hi + lo = w * scale to 2^-22 relative)
+__global__ void split_weights_f16_kernel(const float* w, bf16_t* out, long n, float scale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float x = w[i] * scale;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        const long blk = i >> 5, e = i & 31;
+        out[blk * 64 + e] = __builtin_bit_cast(bf16_t, h);
+        out[blk * 64 + 32 + e] = __builtin_bit_cast(bf16_t, l);
+    }
+}
+
+extern "C" int uv_split_weights_f16x3(const float* w, void* out, long n, float scale, void* stream) {
+    int ex = 0;
+    UV_CHECK_ARG(w && out && n > 0 && n % 32 == 0, "uv_split_weights_f16x3: n must be a positive multiple of 32");
+    UV_CHECK_ARG(scale > 0.f && frexpf(scale, &ex) == 0.5f, "uv_split_weights_f16x3: scale=%g must be a power of two", (double)scale);
+    hipLaunchKernelGGL(split_weights_f16_kernel, dim3((unsigned)min((n + 255) / 256, (long)4096)), dim3(256), 0, (hipStream_t)stream, w,
+                       (bf16_t*)out, n, scale);
+    UV_CHECK_LAUNCH("uv_split_weights_f16x3");
     return 0;
 }
 

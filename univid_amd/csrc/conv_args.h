@@ -14,6 +14,7 @@ struct ConvArgs {
     int Tout, Hout, Wout, Tin, Hin, Win;
     int Cin, Cout, kt, kh, kw, st, sh, sw, t_off, ph, pw, up, interleave;
     int M, tiles_m, tiles_n;
+    float out_scale;     // f16x3 (PREC 4): the accumulators carry the power-of-two scale of the split weights; out = acc * out_scale + bias
 };
 
 // conv3d_halo.hip

@@ -60,7 +60,19 @@ __global__ __launch_bounds__(256) void vae_rms_silu_kernel(const float* in, long
                 y[e] = t;
             }
             if (c4 < nv) {
-                if (split_out) {
+                if (split_out == 2) {        // two IEEE fp16 pieces (uv_conv3d_f16x3): hi = fp16(y), lo = fp16(y - hi)
+                    const int c = c4 * 4;
+                    bf16_t* ob = (bf16_t*)(out + row * ld_out) + (c >> 5) * 64 + (c & 31);
+                    _Float16 hi[4], lo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hi[e] = (_Float16)y[e];
+                        lo[e] = (_Float16)(y[e] - (float)hi[e]);
+                    }
+                    auto pk = [](_Float16 a, _Float16 b) { return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16); };
+                    *(u32x2*)ob = (u32x2){pk(hi[0], hi[1]), pk(hi[2], hi[3])};
+                    *(u32x2*)(ob + 32) = (u32x2){pk(lo[0], lo[1]), pk(lo[2], lo[3])};
+                } else if (split_out) {
                     const int c = c4 * 4;
                     bf16_t* ob = (bf16_t*)(out + row * ld_out) + (c >> 5) * 64 + (c & 31);
                     float lo[4];

@@ -358,7 +358,9 @@ def _zeros_cached(key, shape, dtype, device):
     """Zero-initialised scratch whose padding region is never written (V^T column padding). One tensor per key: a new shape
     replaces the old one (the caching allocator frees it in stream order), so the cache does not grow with the resolutions served."""
     t = _zero_cache.get(key)
-    if t is None or tuple(t.shape) != tuple(shape):
+    # (a scratch created under torch.inference_mode() cannot be re-zeroed in place outside it - e.g. by a HIP-graph capture, which runs
+    # outside inference mode -: such a tensor is replaced)
+    if t is None or tuple(t.shape) != tuple(shape) or (t.is_inference() and not torch.is_inference_mode_enabled()):
         t = torch.zeros(shape, dtype=dtype, device=device)
         _zero_cache[key] = t
     return t

@@ -99,20 +99,24 @@ class _GraphedPair:
         self.key = key
         L = seq_len
         self.model = model
-        self.lat = torch.empty_like(latent)
-        n_t = 1 if i2v_mask is None else 2
-        self.tvals = torch.zeros(n_t, dtype=torch.float32, device=dev)
-        if i2v_mask is None:
-            tid = None
-        else:   # mask 0 (first latent frame) -> row 0 (timestep 0), mask 1 -> row 1 (timestep t); padding tokens never exist here
-            one = i2v_mask.to(torch.int32)
-            tid = torch.cat([one, one]).contiguous()
-        ctx = [context[0], context_null[0]]
-        self.lat.copy_(latent)
         self.dev = dev
-        # capture and replay with the latent's device current: torch's capture stream belongs to the current device, and the
-        # kernels follow the device of their tensors (a model on cuda:1 in a process whose current device is cuda:0)
-        with torch.no_grad(), torch.cuda.device(dev):
+        # Everything the graph owns is allocated, and the capture is taken, OUTSIDE inference mode: torch's capture_begin updates its
+        # own (normal) generator-state tensors in place and raises under torch.inference_mode() ("Inplace update to inference tensor
+        # outside InferenceMode" - found by round 4's test of exactly that serving set-up). Reading the caller's inference tensors from
+        # here is allowed; the static buffers below are normal tensors, which inference-mode code may write in place.
+        # Capture and replay run with the latent's device current: torch's capture stream belongs to the current device, and the
+        # kernels follow the device of their tensors (a model on cuda:1 in a process whose current device is cuda:0).
+        with torch.inference_mode(False), torch.no_grad(), torch.cuda.device(dev):
+            self.lat = torch.empty(latent.shape, dtype=latent.dtype, device=dev)
+            n_t = 1 if i2v_mask is None else 2
+            self.tvals = torch.zeros(n_t, dtype=torch.float32, device=dev)
+            if i2v_mask is None:
+                tid = None
+            else:   # mask 0 (first latent frame) -> row 0 (timestep 0), mask 1 -> row 1 (timestep t); padding tokens never exist here
+                one = i2v_mask.to(torch.int32)
+                tid = torch.cat([one, one]).contiguous()
+            ctx = [context[0], context_null[0]]
+            self.lat.copy_(latent)
             # eager warm-up on the capture inputs: weight preparation, context cache, scratch buffers, function attributes
             model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid))
             torch.cuda.synchronize(dev)

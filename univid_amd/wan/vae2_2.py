@@ -170,6 +170,7 @@ class _ConvOp:
         self.b = conv.bias.detach().float().contiguous()
         self.w_split = None
         self.w_split6 = None
+        self.w_split_f16 = None      # (fp16 hi | lo pieces of w * scale, scale) for the f16x3 kernel
         self.caches = {}     # (H, W, prefix) -> the cached frames [prefix, H, W, cin_pad] (zeros = the causal zero padding)
         self.rings = {}      # private input rings of the few convolutions whose channel count is padded (see _Engine.conv_input)
 
@@ -187,6 +188,18 @@ class _ConvOp:
             _lib.call("uv_split_weights_bf16x6", _lib.ptr(self.w), _lib.ptr(self.w_split6), self.w.numel(), _lib.stream_ptr())
         return self.w_split6
 
+    def split_f16(self):
+        """two IEEE fp16 pieces of w * scale ([Cout][K/32][32 hi | 32 lo]) for the f16x3 kernel; scale = the power of two that puts
+        max |w| into [2^13, 2^14): all but the smallest weights then have NORMAL lo pieces (fp16 subnormals start below 2^-14), and
+        65 504 is far away. The kernel undoes the scale exactly in its epilogue."""
+        if self.w_split_f16 is None:
+            mx = float(self.w.abs().max())
+            scale = 2.0 ** (13 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+            buf = torch.empty(self.w.numel() * 2, dtype=torch.float16, device=self.w.device)
+            _lib.call("uv_split_weights_f16x3", _lib.ptr(self.w), _lib.ptr(buf), self.w.numel(), float(scale), _lib.stream_ptr())
+            self.w_split_f16 = (buf, float(scale))
+        return self.w_split_f16
+
     def cache(self, H, W, prefix=CACHE_T):
         key = (H, W, prefix)
         c = self.caches.get(key)
@@ -197,9 +210,10 @@ class _ConvOp:
 
 class _Engine:
     def __init__(self, model: "WanVAE_", precision="fp32"):
-        if precision not in ("fp32", "bf16x6", "bf16x3"):
+        if precision not in ("fp32", "bf16x6", "f16x3", "bf16x3"):
             raise ValueError("precision must be 'fp32' (f32 MFMA, like the reference), 'bf16x6' (f32-grade: exact 3-way operand "
-                             "splitting on the bf16 MFMA) or 'bf16x3' (2-way split, ~1e-5)")
+                             "splitting on the bf16 MFMA), 'f16x3' (f32-grade: 2-way fp16 splitting, 3 passes, for the convolutions "
+                             "behind an RMS_norm; bf16x6 elsewhere) or 'bf16x3' (2-way bf16 split, ~1e-5)")
         self.m = model
         self.precision = precision
         self.ops = {}
@@ -210,6 +224,22 @@ class _Engine:
                 self.ops[mod] = _ConvOp(mod, is2d=True)
         self.dev = next(model.parameters()).device
         self.scratch = {}    # (H, W, channels) -> shared conv-input buffer [frames, H, W, channels]
+        self._fmt = {}       # RMS_norm module -> activation format its output is written in (see split_fmt)
+
+    def split_fmt(self, norm, cin, cout):
+        """Format in which RMS_norm (+ SiLU) writes the input of the convolution behind it: 0 = f32 rows, 1 = two bf16 pieces per
+        element (bf16x3), 2 = two IEEE fp16 pieces (f16x3). The fp16 form needs |activation| < 65 504: an RMS-normalised row is bounded
+        by sqrt(C) * max|gamma| (|x_i| / ||x|| <= 1; SiLU does not grow a magnitude), checked here ONCE per norm; a norm whose bound
+        does not hold keeps f32 rows and its convolution runs as bf16x6 (exact splitting, no range limit)."""
+        if cin % 32 or cout % 4 or self.precision not in ("bf16x3", "f16x3"):
+            return 0
+        if self.precision == "bf16x3":
+            return 1 if cout % 32 == 0 else 0
+        f = self._fmt.get(norm)
+        if f is None:
+            bound = math.sqrt(norm.gamma.numel()) * float(norm.gamma.detach().abs().max())
+            f = self._fmt[norm] = 2 if bound < 6.0e4 else 0
+        return f
 
     def reset(self):
         """WanVAE_.clear_cache (vae2_2.py:853-860): all cached frames back to the causal zero padding."""
@@ -252,7 +282,7 @@ class _Engine:
 
     # -- kernels --
     def _conv(self, op, src, Tin, Hin, Win, Tout, Hout, Wout, st=1, sh=1, sw=1, t_off=0, ph=0, pw=0, up=0, interleave=0,
-              resid=None, out=None, ldo=None, in_split=False):
+              resid=None, out=None, ldo=None, in_split=0):
         cout = op.cout // 2 if interleave else op.cout
         tt = Tout * 2 if interleave else Tout
         if out is None:
@@ -263,14 +293,18 @@ class _Engine:
                 _lib.ptr(resid), 0 if resid is None else resid.stride(-2))
         if self.precision == "bf16x3":
             _lib.call("uv_conv3d_bf16x3", _lib.ptr(src), src.stride(-2), Tin, Hin, Win, _lib.ptr(op.split()), _lib.ptr(op.b),
-                      _lib.ptr(out), *geom, int(in_split), _lib.stream_ptr(), flops=flops)
+                      _lib.ptr(out), *geom, int(in_split == 1), _lib.stream_ptr(), flops=flops)
+        elif self.precision == "f16x3" and in_split == 2:
+            wsp, wscale = op.split_f16()
+            _lib.call("uv_conv3d_f16x3", _lib.ptr(src), src.stride(-2), Tin, Hin, Win, _lib.ptr(wsp), _lib.ptr(op.b), _lib.ptr(out),
+                      *geom, wscale, _lib.stream_ptr(), flops=flops)
         else:
-            x6 = self.precision == "bf16x6"
+            x6 = self.precision in ("bf16x6", "f16x3")         # f16x3: convolutions whose input is not an RMS_norm output
             _lib.call("uv_conv3d_bf16x6" if x6 else "uv_conv3d_f32", _lib.ptr(src), src.stride(-2), Tin, Hin, Win,
                       _lib.ptr(op.split6() if x6 else op.w), _lib.ptr(op.b), _lib.ptr(out), *geom, _lib.stream_ptr(), flops=flops)
         return out
 
-    def _rms_silu(self, x, gamma, out, silu=True, split=False):
+    def _rms_silu(self, x, gamma, out, silu=True, split=0):
         P = x.numel() // x.shape[-1]
         _lib.call("uv_vae_rms_silu", _lib.ptr(x), x.stride(-2), _lib.ptr(gamma), _lib.ptr(out), out.stride(-2), P, x.shape[-1],
                   int(silu), int(split), _lib.stream_ptr())
@@ -284,9 +318,10 @@ class _Engine:
         return out
 
     # -- blocks --
-    def causal_conv(self, conv, fill, T, H, W, resid=None, in_split=False):
+    def causal_conv(self, conv, fill, T, H, W, resid=None, in_split=0):
         """3x3x3 causal conv over [cache(2) | T frames]; `fill(dst)` writes the current frames.
-        in_split: the filler writes split-bf16 activations (bf16x3 mode; zeros stay zeros, so the cache logic is unchanged)."""
+        in_split: the filler writes split activations (1 = bf16 pieces, bf16x3 mode; 2 = fp16 pieces, f16x3 mode; zeros stay zeros,
+        so the cache logic is unchanged)."""
         op = self.ops[conv]
         ring, after = self.conv_input(op, H, W, T, fill)
         y = self._conv(op, ring, CACHE_T + T, H, W, T, H, W, t_off=0, ph=1, pw=1, resid=resid, in_split=in_split)
@@ -299,9 +334,9 @@ class _Engine:
         T, H, W, C = x.shape
         res = blk.residual
         h = x if isinstance(blk.shortcut, nn.Identity) else self._pointwise(self.ops[blk.shortcut], x)
-        sp = self.precision == "bf16x3" and C % 32 == 0 and blk.out_dim % 32 == 0
-        y = self.causal_conv(res[2], lambda dst: self._rms_silu(x, res[0].gamma, dst, split=sp), T, H, W, in_split=sp)
-        return self.causal_conv(res[6], lambda dst: self._rms_silu(y, res[3].gamma, dst, split=sp), T, H, W, resid=h, in_split=sp)
+        sp1, sp2 = self.split_fmt(res[0], C, blk.out_dim), self.split_fmt(res[3], blk.out_dim, blk.out_dim)
+        y = self.causal_conv(res[2], lambda dst: self._rms_silu(x, res[0].gamma, dst, split=sp1), T, H, W, in_split=sp1)
+        return self.causal_conv(res[6], lambda dst: self._rms_silu(y, res[3].gamma, dst, split=sp2), T, H, W, resid=h, in_split=sp2)
 
     def attention(self, blk, x):
         """AttentionBlock.forward vae2_2.py:255-277: per-frame single-head attention, head_dim = C, fp32."""
@@ -382,7 +417,7 @@ class _Engine:
         x = self.attention(enc.middle[1], x)
         x = self.resblock(enc.middle[2], x)
         T2, H2, W2, _ = x.shape
-        sp = self.precision == "bf16x3" and x.shape[-1] % 32 == 0
+        sp = self.split_fmt(enc.head[0], x.shape[-1], 32)
         return self.causal_conv(enc.head[2], lambda dst: self._rms_silu(x, enc.head[0].gamma, dst, split=sp), T2, H2, W2, in_split=sp)
 
     def decoder_chunk(self, xin, first_chunk):
@@ -404,7 +439,7 @@ class _Engine:
                           (ft - 1) if first_chunk else 0, _lib.stream_ptr())
             x = xm
         T, Hh, Ww, _ = x.shape
-        sp = self.precision == "bf16x3" and x.shape[-1] % 32 == 0
+        sp = self.split_fmt(dec.head[0], x.shape[-1], 32)
         return self.causal_conv(dec.head[2], lambda dst: self._rms_silu(x, dec.head[0].gamma, dst, split=sp), T, Hh, Ww, in_split=sp)
 
 
@@ -435,8 +470,10 @@ class WanVAE_(nn.Module):
     def prepare(self, precision=None):
         """precision: 'fp32' = exact f32 MFMA (the reference's dtype, default) | 'bf16x6' = the same f32 operands, products on the
         bf16 matrix pipe by exact three-way operand splitting (6 passes; as close to an fp64 convolution as the f32 MFMA kernel,
-        1.45 x faster) | 'bf16x3' = two-way split, 3 passes (~1e-5 relative error, several times faster). The 1x1 convolutions,
-        norms and the per-frame attention stay on the f32 kernels in every mode."""
+        1.45 x faster) | 'f16x3' = f32-grade too, in 3 passes: the convolutions behind an RMS_norm (ResidualBlocks, heads: ~90 % of
+        the FLOPs) take both operands as two IEEE fp16 pieces (22 significant bits; their error against fp64 equals the f32 MFMA's,
+        which is accumulation-bound), the others run as bf16x6 | 'bf16x3' = two-way bf16 split, 3 passes (~1e-5 relative error).
+        The 1x1 convolutions, norms and the per-frame attention stay on the f32 kernels in every mode."""
         if next(self.parameters()).device.type != "cuda":
             raise _lib.UnividHipError("WanVAE_.prepare: parameters must be on the GPU - there is no CPU path in univid_amd")
         _lib.init()
