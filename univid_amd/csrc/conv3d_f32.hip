@@ -390,6 +390,11 @@ static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, c
         UV_CHECK_LAUNCH("uv_conv3d (halo)");
         return 0;
     }
+    if (prec == 4 && uv_conv3d_halo16_eligible(a)) {      // f16x3: its own LDS-halo kernel (pre-split operands, halo filled by LDS-DMA)
+        uv_launch_conv3d_halo16(a, s);
+        UV_CHECK_LAUNCH("uv_conv3d_f16x3 (halo)");
+        return 0;
+    }
     // tile choice: 256x256 (16 waves, 4 per SIMD) when Cout >= 256 and the grid still fills the chip: halves the A gather
     // per output; 256x128 (8 waves) next; the 4-wave 128x128 tile for the low-resolution stages
     const long t256 = (long)((a.M + 255) / 256) * ((Cout + 255) / 256);

@@ -1,0 +1,209 @@
+// The LDS-halo implicit GEMM of conv3d_halo.hip for the f32-grade THREE-pass fp16 arithmetic ("f16x3", PREC 4 of conv3d_f32.hip): the 3x3(x3)
+// stride-1 convolutions behind an RMS_norm (ResidualBlocks: ~75 % of the decoder's time in that mode), both operands PRE-SPLIT into two
+// IEEE fp16 pieces per element.
+//
+// Replaces (reference, fp32 nn.Conv3d through cuDNN): CausalConv3d.forward  models/wan/utils/modules/vae2_2.py:17-42 as used by
+// ResidualBlock (vae2_2.py:193-235); arithmetic contract = conv3d_f32_kernel<.., 4> (x*w ~ xh*wh + xh*wl + xl*wh on
+// v_mfma_f32_16x16x32_f16, f32 accumulate, out = acc * out_scale + bias (+ residual)); only the k ORDER of the sum differs (taps inside a
+// channel block here, channel blocks inside a tap there), so the two agree to f32 summation noise, not bit for bit - the choice between
+// them depends on per-FRAME geometry only, never on the pass length (pass-length independence is bit-exact and tested).
+//
+// Against conv3d_halo_kernel<3, 32> (bf16x6):
+//   * the activations arrive pre-split ([C/32][32 hi | 32 lo] fp16 per pixel = the 128 bytes of 32 f32 channels, written by
+//     uv_vae_rms_silu(split_out = 2)), so the halo image (8 x 32 patch + one-pixel rim = 340 pixels x 128 B) is filled by LDS-DMA straight
+//     from global memory - no register staging, no conversion work in this kernel at all; out-of-frame pixels read the zero page;
+//   * two halo images: the pieces of channel group g+1 are issued ONE PER TAP during taps 0..5 of group g, each right in front of that
+//     tap's weight pieces, so every LDS-DMA piece of the loop has one tap of MFMA work (48 MFMAs per wave) to land in;
+//   * weights: [Cout][K/32][32 hi | 32 lo] fp16 of w * 2^s (uv_split_weights_f16x3), one k-tile = (tap, 32 channels) = 128 B per output
+//     channel, double-buffered, one barrier per tap;
+//   * 8 waves = 4 (pixel rows) x 2 (output-channel halves), a wave owns 64 pixels x 64 channels: 16 accumulator fragments, 3 MFMAs each
+//     per tap; fragment reads: 16 ds_read_b128 per 48 MFMAs and wave (a third of the LDS bandwidth), bank-conflict-free by the XOR
+//     swizzle chunk ^= (row >> 1) & 7 on 128-byte rows (applied on the DMA's source address and on the read).
+#include "conv_args.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(3))) void lds_void_g;
+
+template <int BN = 128>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3d_halo_f16_kernel(ConvArgs p) {
+    constexpr int TW = 32, TH = 8, HW_ = TW + 2, NHP = (TH + 2) * HW_;       // 340 halo pixels
+    constexpr int NW = 8, TM = 4, TN = BN / 32;
+    constexpr int H_PIECES = (NHP + 7) / 8;                                  // 43 one-KiB pieces (8 pixels x 128 B)
+    constexpr int HALO_BYTES = H_PIECES * 1024;                              // 44 032
+    constexpr int H_INSTR = (H_PIECES + NW - 1) / NW;                        // 6 (waves 0..2) / 5
+    constexpr int W_BYTES = BN * 128, W_INSTR = W_BYTES / 1024 / NW;         // 16 KiB, 2 pieces per wave
+    static_assert(H_INSTR <= 6, "one halo piece per tap during taps 0..5");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wbuf = smem + 2 * HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_w = (p.Wout + TW - 1) / TW, tiles_h = (p.Hout + TH - 1) / TH;
+    const int tile_n = blockIdx.x % p.tiles_n;
+    int mt = blockIdx.x / p.tiles_n;
+    const int tx0 = (mt % tiles_w) * TW;
+    mt /= tiles_w;
+    const int ty0 = (mt % tiles_h) * TH;
+    const int tf = mt / tiles_h;                                             // output frame
+    const int n0 = tile_n * BN;
+    const int K = p.kt * 9 * p.Cin;
+    const long frame = (long)p.Hin * p.Win * p.ld_in;
+
+    // ---- halo staging map: piece pi = it * 8 + wave covers halo pixels 8 pi .. 8 pi + 7; lane -> pixel lane >> 3, physical chunk lane & 7
+    long h_off[H_INSTR];             // f32-sized element offset of this lane's chunk inside a frame (channel block 0)
+    unsigned h_ok = 0;               // bit it: inside the frame
+#pragma unroll
+    for (int it = 0; it < H_INSTR; ++it) {
+        const int hp = (it * NW + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((hp >> 1) & 7);                          // logical 16-byte chunk stored at physical chunk lane & 7
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;                        // coordinates in the convolution's input image
+        const bool ok = hp < NHP && (unsigned)y < (unsigned)p.Hout && (unsigned)x < (unsigned)p.Wout;
+        h_ok |= (unsigned)ok << it;
+        const int sy = p.up ? y >> 1 : y, sx = p.up ? x >> 1 : x;            // up: nearest-exact 2x (vae2_2.py:86-96)
+        h_off[it] = ok ? ((long)sy * p.Win + sx) * p.ld_in + c * 4 : 0;
+    }
+    const int ncb = p.Cin >> 5, ngroups = p.kt * ncb;                        // group g = (dt, channel block cb)
+    auto stage_halo_piece = [&](int g, int it, int hb) __attribute__((always_inline)) {
+        if (it * NW + wave >= H_PIECES) return;
+        const int dt = g / ncb, cb = g - dt * ncb;
+        const int fi = tf * p.st + p.t_off + dt;
+        const bool ok = (unsigned)fi < (unsigned)p.Tin && ((h_ok >> it) & 1u);
+        const float* src = ok ? p.in + (long)fi * frame + cb * 32 + h_off[it] : p.zeros;
+        __builtin_amdgcn_global_load_lds((const void*)src, (lds_void_g*)(smem + hb * HALO_BYTES + (it * NW + wave) * 1024), 16, 0, 0);
+    };
+
+    // ---- weight staging: piece = 8 output channels x 128 B of one k-tile
+    const int srow = lane >> 3, pchunk = lane & 7;
+    const float* w_src[W_INSTR];
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i) {
+        const int row = (i * NW + wave) * 8 + srow;
+        w_src[i] = p.w + (long)min(n0 + row, p.Cout - 1) * K + (pchunk ^ ((row >> 1) & 7)) * 4;
+    }
+    auto stage_w = [&](int g, int tap, int wb) __attribute__((always_inline)) {
+        const int dt = g / ncb, cb = g - dt * ncb;
+        const int koff = ((dt * 9 + tap) * ncb + cb) * 32;                   // k order of the weight matrix: tap-major, channels minor
+#pragma unroll
+        for (int i = 0; i < W_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(w_src[i] + koff), (lds_void_g*)(wbuf + wb * W_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    int hpb[TM];                     // halo pixel of this lane's output pixel of fragment j for tap (0, 0)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) hpb[j] = (wm * 2 + (j >> 1)) * HW_ + (j & 1) * 16 + frow;
+    int w_off[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int row = wn * (BN / 2) + i * 16 + frow;
+        w_off[i] = row * 128 + ((fq ^ ((row >> 1) & 7)) << 4);               // hi piece; lo piece = the same address ^ 64
+    }
+
+    auto compute = [&](int tap, const char* wb, const char* halo) __attribute__((always_inline)) {
+        const int dh = tap / 3, dw = tap - dh * 3;
+        const int toff = dh * HW_ + dw;
+        bf16x8 ah[TM], al[TM], wh[TN], wl[TN];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int hp = hpb[j] + toff;
+            const int o = hp * 128 + ((fq ^ ((hp >> 1) & 7)) << 4);
+            ah[j] = *(const bf16x8*)(halo + o);
+            al[j] = *(const bf16x8*)(halo + (o ^ 64));
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            wh[i] = *(const bf16x8*)(wb + w_off[i]);
+            wl[i] = *(const bf16x8*)(wb + (w_off[i] ^ 64));
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                acc[i][j] = mfma_16x16x32<true>(wl[i], ah[j], acc[i][j]);    // smallest terms first (as conv3d_f32_kernel PREC 4)
+                acc[i][j] = mfma_16x16x32<true>(wh[i], al[j], acc[i][j]);
+                acc[i][j] = mfma_16x16x32<true>(wh[i], ah[j], acc[i][j]);
+            }
+    };
+
+    // ---- pipeline: one barrier per tap; weights of the next tap and (taps 0..5) one halo piece of the next group in flight behind the MFMAs
+#pragma unroll
+    for (int it = 0; it < H_INSTR; ++it) stage_halo_piece(0, it, 0);
+    stage_w(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int wb = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        const bool more = g + 1 < ngroups;
+        const int hb = g & 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // (the other halo image was last read in group g-1, whose final barrier every wave has passed)
+            if (tap < H_INSTR && more) stage_halo_piece(g + 1, tap, hb ^ 1);
+            if (tap < 8) stage_w(g, tap + 1, wb ^ 1);
+            else if (more) stage_w(g + 1, 0, wb ^ 1);
+            compute(tap, wbuf + wb * W_BYTES, smem + hb * HALO_BYTES);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            wb ^= 1;
+        }
+    }
+
+    // ---- epilogue: exact power-of-two descale, bias, optional residual, f32 store
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int py = wm * 2 + (j >> 1), px = (j & 1) * 16 + frow;
+        const int y = ty0 + py, x = tx0 + px;
+        if (y >= p.Hout || x >= p.Wout) continue;
+        const long m = ((long)tf * p.Hout + y) * p.Wout + x;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + wn * (BN / 2) + i * 16 + 4 * fq;
+            if (n >= p.Cout) continue;
+            f32x4 v = acc[i][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+            if (p.bias) {
+                const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += b[e];
+            }
+            if (p.resid) {
+                const f32x4 rr = *(const f32x4*)(p.resid + m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rr[e];
+            }
+            *(f32x4*)(p.out + m * p.ldo + n) = v;
+        }
+    }
+}
+
+// Which f16x3 convolutions take this kernel: the geometry rule of uv_conv3d_halo_eligible (3x3 spatial taps, stride 1, padding 1, plain or
+// behind the 2x upsampling, whole 32-channel input blocks and 128-wide output tiles) and enough tiles PER FRAME to fill the chip at four
+// frames per pass. uv_set_option(UV_OPT_CONV_HALO, 0 | 1) forces never / whenever the geometry fits, as for the other arithmetics.
+bool uv_conv3d_halo16_eligible(const ConvArgs& a) {
+    const int force = uv_option(UV_OPT_CONV_HALO);
+    if (force == 0) return false;
+    if (a.kh != 3 || a.kw != 3 || (a.kt != 3 && a.kt != 1)) return false;
+    if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.interleave) return false;
+    const int mul = a.up ? 2 : 1;
+    if (a.Hin * mul != a.Hout || a.Win * mul != a.Wout || a.Cout % 128 != 0 || a.Cin % 32 != 0) return false;
+    const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * (a.Cout / 128);
+    return force == 1 || 4 * tiles >= uv_num_cus();
+}
+
+int uv_launch_conv3d_halo16(ConvArgs& a, hipStream_t stream) {
+    a.tiles_n = a.Cout / 128;
+    a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
+    const size_t lds = 2 * 43 * 1024 + 2 * 128 * 128;                        // two halo images + two weight tiles = 118 KiB
+    UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)conv3d_halo_f16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((conv3d_halo_f16_kernel<128>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+    return 0;
+}

@@ -1,5 +1,5 @@
-// Argument block of the VAE convolution kernels (conv3d_f32.hip: gather kernel, every geometry; conv3d_halo.hip: LDS-halo kernel for
-// the 3x3(x3) stride-1 convolutions).
+// Argument block of the VAE convolution kernels (conv3d_f32.hip: gather kernel, every geometry; conv3d_halo.hip / conv3d_halo16.hip: LDS-halo
+// kernels for the 3x3(x3) stride-1 convolutions).
 #pragma once
 #include "common.h"
 
@@ -20,3 +20,6 @@ struct ConvArgs {
 // conv3d_halo.hip
 bool uv_conv3d_halo_eligible(const ConvArgs& a, int prec);
 int uv_launch_conv3d_halo(ConvArgs& a, int prec, hipStream_t stream);
+// conv3d_halo16.hip (f16x3)
+bool uv_conv3d_halo16_eligible(const ConvArgs& a);
+int uv_launch_conv3d_halo16(ConvArgs& a, hipStream_t stream);
