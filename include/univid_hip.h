@@ -180,6 +180,11 @@ int uv_dpmpp_update(const float* x, const float* m0, const float* m1, float* out
  * (tap-major, channel-minor); out rows = output pixels (t,h,w) row-major, [M, ldo]. Input frame of tap dt for output
  * frame t is t*st + dt + t_off; rows/cols are h*sh + dh - ph, w*sw + dw - pw, out-of-range taps contribute zero.
  * up=1: the input is read through a nearest-exact 2x spatial upsample (Hin/Win are the PRE-upsample sizes).
+ * up=2+2a+b (a, b in {0,1}): ONE OUTPUT PHASE of such an upsampling 3x3 convolution. On the 2x nearest-upsampled image the three taps
+ * of a row collapse onto two source rows (phase a=0: {dy=0} -> y-1, {1,2} -> y; a=1: {0,1} -> y, {2} -> y+1; columns alike), so output
+ * pixels (2y+a, 2x+b) are a 2x2 convolution of the SOURCE image with the pre-summed weights of the collapsed taps: 16 instead of 36
+ * multiply-adds per four output pixels. The launch takes that 2x2 kernel (kh = kw = 2, ph = 1-a, pw = 1-b), Hout/Wout = the SOURCE
+ * resolution, and stores pixel (t, y, x) at (t, 2y+a, 2x+b) of the [Tout, 2 Hout, 2 Wout, ldo] output; four launches make the layer.
  * interleave=1: output channel halves become consecutive frames (Resample.time_conv, vae2_2.py:143-151).
  * Cin % 32 == 0 (zero-pad channels), Cout % 4 == 0. */
 int uv_conv3d_f32(const float* in, long ld_in, int Tin, int Hin, int Win, const float* w, const float* bias, float* out,
@@ -210,10 +215,17 @@ int uv_split_weights_bf16x3(const float* w, void* out, long n, void* stream);
  * `in` holds PRE-SPLIT activations ([C/32][32 hi | 32 lo] fp16 per pixel = the bytes of an f32 pixel; written by uv_vae_rms_silu(split_out=2);
  * |x| < 65 504: an RMS-normalised row is bounded by sqrt(C) max|gamma|, which the caller checks); w_split = uv_split_weights_f16x3(w, w_scale)
  * with w_scale a power of two (max|w| * w_scale in [2^13, 2^14) keeps the lo pieces normal); out = acc / w_scale + bias (+ resid), f32.
+ * act_scale: NULL, or a DEVICE scalar the result is multiplied by too - the 1 / s of activations split by uv_vae_split_f16 under a
+ * per-tensor power-of-two scale (convolutions whose input is not an RMS_norm output: Resample, vae2_2.py:86-108).
  * Replaces the same reference lines as uv_conv3d_f32 for the convolutions that follow an RMS_norm (ResidualBlock, heads: vae2_2.py:193-235). */
 int uv_conv3d_f16x3(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w_split, const float* bias, float* out, long ldo,
                     int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw, int t_off, int ph,
-                    int pw, int up, int interleave, const float* resid, long ldr, float w_scale, void* stream);
+                    int pw, int up, int interleave, const float* resid, long ldr, float w_scale, const float* act_scale, void* stream);
+/* x [P, C] f32 rows (any feature map; C % 32 == 0) -> `out`: the same bytes per pixel holding [C/32][32 hi | 32 lo] IEEE fp16 pieces of
+ * x * s, s a per-tensor power of two found on the device: 1 while max|x| < 2^15 (then this equals uv_vae_rms_silu's split_out=2 format of
+ * the same values), else the scale that puts max|x| into [2^14, 2^15). scale: two device floats; scale[0] <- 1 / s for uv_conv3d_f16x3's
+ * act_scale, scale[1] = work space. Three stream-ordered operations (memset, max-reduction, split); no host round trip. */
+int uv_vae_split_f16(const float* x, long ld, float* out, long ld_out, long P, int C, float* scale, void* stream);
 /* w [n] f32 (rows of K, K % 32 == 0) -> [n/32][32 hi | 32 lo] IEEE fp16 with hi = fp16(w * scale), lo = fp16(w * scale - hi); scale = 2^s */
 int uv_split_weights_f16x3(const float* w, void* out, long n, float scale, void* stream);
 /* y = x / max(||x||,1e-12) * sqrt(C) * gamma [-> SiLU] per pixel (RMS_norm + SiLU, vae2_2.py:45-59, 201-206).

@@ -1876,6 +1876,56 @@ def test_vae_f16x3_precision_mode_vs_golden():
     assert_f32_close(pair["f16x3"], pair["fp32"], name="f16x3 with one norm outside fp16's range vs exact f32")
 
 
+def test_vae_split_f16_per_tensor_scale():
+    """uv_vae_split_f16 (fp16 pieces of a RAW feature map for uv_conv3d_f16x3: Resample's convolutions read un-normed residual-stream rows):
+    for ordinary magnitudes the scale is 1 and the bytes equal the unscaled split; with an element of 3e6 - beyond fp16's range - the
+    device picks the power of two that brings the maximum into [2^14, 2^15), reports its inverse, and the convolution fed with both is
+    finite and as close to F.conv3d as the exact kernel (relative to the output's scale)."""
+    import torch.nn.functional as F
+    from univid_amd import _lib
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(1, 64, 2, 9, 11, generator=g)
+    w, b = torch.randn(128, 64, 1, 3, 3, generator=g) * 0.05, torch.randn(128, generator=g)
+    wp = w.permute(0, 2, 3, 4, 1).reshape(128, -1).contiguous().to(DEV)
+    wsp, wscale = _split_f16_weights(wp)
+    for big in (False, True):
+        xx = x.clone()
+        if big:
+            xx[0, 5, 1, 4, 6] = 3.0e6
+            xx[0, 9, 0, 0, 0] = -7.0e4
+        x_cl = xx[0].permute(1, 2, 3, 0).contiguous().to(DEV)
+        xs, sc = torch.empty_like(x_cl), torch.full((2,), 7.0, device=DEV)
+        _lib.call("uv_vae_split_f16", _lib.ptr(x_cl), 64, _lib.ptr(xs), 64, x_cl.numel() // 64, 64, _lib.ptr(sc), _lib.stream_ptr())
+        inv = float(sc[0])
+        if not big:
+            assert inv == 1.0 and torch.equal(xs.view(torch.int32), _split_f16_acts(x_cl).view(torch.int32))
+        else:
+            assert inv == 2.0 ** 7 and float(sc[1]) == 3.0e6, (inv, float(sc[1]))       # 3e6 / 128 = 23 437 in [2^14, 2^15)
+            assert torch.isfinite(xs.view(torch.float16).float()).all()
+        out = torch.empty(2, 9, 11, 128, device=DEV)
+        _lib.call("uv_conv3d_f16x3", _lib.ptr(xs), 64, 2, 9, 11, _lib.ptr(wsp), _lib.ptr(b.to(DEV)), _lib.ptr(out), 128, 2, 9, 11, 64, 128,
+                  1, 3, 3, 1, 1, 1, 0, 1, 1, 0, 0, None, 0, wscale, _lib.ptr(sc), _lib.stream_ptr())
+        ref = F.conv3d(F.pad(xx.double(), (1, 1, 1, 1)), w.double(), b.double())[0].permute(1, 2, 3, 0)
+        err = (out.cpu().double() - ref).abs().max().item()
+        assert torch.isfinite(out).all() and err <= 2e-6 * float(ref.abs().max()) + 1e-5, (big, err, float(ref.abs().max()))
+
+
+def test_vae_phase_upsample_equals_the_3x3_form():
+    """The fast modes run Resample's "nearest-exact 2x + 3x3 convolution" as four 2x2 output-phase convolutions with pre-summed weights
+    (2.25 x fewer multiply-adds, _ConvOp.phases): the decode must agree with the 3x3 form of the same mode to f32 rounding noise, incl.
+    the first chunk ("Rep") and the time-upsampling stages; precision='fp32' never uses it."""
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    g = load_golden("vae_small")
+    for prec in ("bf16x6", "f16x3"):
+        vae = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=g["seed"], precision=prec)
+        with torch.no_grad():
+            a = vae.decode([g["dec_in_0"].to(DEV)])[0]
+            assert vae.model._eng().phase_upsample
+            vae.model._eng().phase_upsample = False
+            b = vae.decode([g["dec_in_0"].to(DEV)])[0]
+        assert not torch.equal(a, b) and (a - b).abs().max() <= 2e-5 * max(1.0, float(b.abs().max())), float((a - b).abs().max())
+
+
 def test_vae_full_width_vs_oracle():
     """The production VAE widths (encoder 160..640, decoder 1024..256 channels, z = 48) on a small clip, fp32 mode and
     bf16x3 mode, against the CPU oracle run here."""
@@ -2009,7 +2059,7 @@ def test_conv3d_kernel_geometries(entry):
         elif entry == "uv_conv3d_f16x3":        # both operands as two fp16 pieces (activations pre-split, as uv_vae_rms_silu writes them)
             wp, scale = _split_f16_weights(wp)
             x_cl = _split_f16_acts(x_cl)
-            extra = (scale,)
+            extra = (scale, None)
         inter = kw.get("interleave", 0)
         out = torch.empty(Tout * (2 if inter else 1), Hout, Wout, co // (2 if inter else 1), device=DEV)
         _lib.call(entry, _lib.ptr(x_cl), C, T, H, W, _lib.ptr(wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), out.shape[-1],
@@ -2031,6 +2081,26 @@ def test_conv3d_kernel_geometries(entry):
     ref = F.conv3d(F.pad(up, (1, 1, 1, 1)), w2, b2)                                        # nearest-exact 2x + 3x3
     got = run(cl(x), w2, b2, 5, 12, 14, ph=1, pw=1, up=1)
     assert_f32_close(got.permute(3, 0, 1, 2), ref[0], rtol=1e-4, atol=1e-4, name="up")
+    # the same layer as four 2x2 OUTPUT-PHASE launches (up = 2 + 2a + b) with the collapsed taps' weights summed beforehand
+    if entry != "uv_conv3d_f16x3":      # (the engine keeps these convolutions - raw, un-normed inputs - off the fp16 pieces)
+        rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+        T_, H_, W_ = 5, 6, 7
+        x_cl = cl(x)
+        outp = torch.full((T_, 2 * H_, 2 * W_, 64), 7.0, device=DEV)
+        for a in (0, 1):
+            for b_ in (0, 1):
+                wp = torch.zeros(64, 64, 1, 2, 2, dtype=torch.float64)
+                for i, dys in enumerate(rows[a]):
+                    for j, dxs in enumerate(rows[b_]):
+                        for dy in dys:
+                            for dx in dxs:
+                                wp[:, :, 0, i, j] += w2[:, :, 0, dy, dx].double()
+                wq = wp.float().permute(0, 2, 3, 4, 1).reshape(64, -1).contiguous().to(DEV)
+                if entry == "uv_conv3d_bf16x6":
+                    wq = _split6(wq)
+                _lib.call(entry, _lib.ptr(x_cl), 64, T_, H_, W_, _lib.ptr(wq), _lib.ptr(b2.to(DEV)), _lib.ptr(outp), 64, T_, H_, W_, 64, 64,
+                          1, 2, 2, 1, 1, 1, 0, 1 - a, 1 - b_, 2 + 2 * a + b_, 0, None, 0, _lib.stream_ptr())
+        assert_f32_close(outp.cpu().permute(3, 0, 1, 2), ref[0], rtol=1e-4, atol=1e-4, name="up as four output phases")
     w3, b3 = torch.randn(128, 64, 3, 1, 1, generator=g) * 0.05, torch.randn(128, generator=g)
     y = F.conv3d(F.pad(x, (0, 0, 0, 0, 2, 0)), w3, b3)                                     # time_conv + interleave
     ref = torch.stack((y[:, :64], y[:, 64:]), 3).reshape(1, 64, 10, 6, 7)
@@ -2074,7 +2144,7 @@ def test_conv3d_halo_kernel_geometries(entry):
         elif entry == "uv_conv3d_f16x3":       # conv3d_halo16.hip: pre-split operands, halo image filled by LDS-DMA
             wp, scale = _split_f16_weights(wp)
             x_cl = _split_f16_acts(x_cl)
-            extra = (scale,)
+            extra = (scale, None)
         out = torch.full((Tout, Hout, Wout, co), 7.0, device=DEV)
         _lib.call(entry, _lib.ptr(x_cl), C, T, H, W, _lib.ptr(wp), _lib.ptr(b.to(DEV)), _lib.ptr(out), co, Tout, Hout, Wout, C, co,
                   kt, kh, kw_, 1, 1, 1, t_off, 1, 1, up, 0, _lib.ptr(resid), 0 if resid is None else co, *extra, _lib.stream_ptr())
@@ -2134,7 +2204,7 @@ def test_conv3d_bf16x6_is_f32_grade():
                 wt = _split6(wp)
             elif name.endswith("f16x3"):
                 wt, scale = _split_f16_weights(wp)
-                src, extra = _split_f16_acts(x_cl), (scale,)
+                src, extra = _split_f16_acts(x_cl), (scale, None)
             _lib.call(name, _lib.ptr(src), C, T + 2, H, W, _lib.ptr(wt), _lib.ptr(b.to(DEV)), _lib.ptr(out), co, T, H, W, C, co, 3, 3, 3,
                       1, 1, 1, 0, 1, 1, 0, 0, None, 0, *extra, _lib.stream_ptr())
             d = out.cpu().double() - ref

@@ -61,7 +61,8 @@ SIGNATURES = {
     "uv_conv3d_bf16x3": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                          _P, _L, _I, _P],
     "uv_conv3d_f16x3": [_P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
-                        _P, _L, _F, _P],
+                        _P, _L, _F, _P, _P],
+    "uv_vae_split_f16": [_P, _L, _P, _L, _L, _I, _P, _P],
     "uv_split_weights_f16x3": [_P, _P, _L, _F, _P],
     "uv_split_weights_bf16x3": [_P, _P, _L, _P],
     "uv_split_weights_bf16x6": [_P, _P, _L, _P],

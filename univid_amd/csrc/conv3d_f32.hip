@@ -325,8 +325,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
             if (n >= p.Cout) continue;
             f32x4 v = acc[i][j];
             if constexpr (PREC == 4) {
+                const float sc = p.act_scale ? p.out_scale * *p.act_scale : p.out_scale;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;        // exact: a power of two
+                for (int e = 0; e < 4; ++e) v[e] *= sc;                 // exact: a power of two
             }
             if (p.bias) {
                 const f32x4 b = *(const f32x4*)(p.bias + n);
@@ -338,6 +339,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_f32_kernel(ConvArgs p) {
                 const int t = m / hw, pix = m - t * hw;
                 const int half = n >= chalf;
                 *(f32x4*)(p.out + ((long)(2 * t + half) * hw + pix) * p.ldo + (n - half * chalf)) = v;
+            } else if (p.ophase >= 0) {
+                // one phase of a 2x-upsampling convolution: pixel (t, y, x) of the source-resolution grid -> (t, 2y + a, 2x + b)
+                const int t = m / hw, pix = m - t * hw, y = pix / p.Wout, x = pix - y * p.Wout;
+                const long orow = ((long)t * 2 * p.Hout + 2 * y + (p.ophase >> 1)) * (2 * p.Wout) + 2 * x + (p.ophase & 1);
+                *(f32x4*)(p.out + orow * p.ldo + n) = v;
             } else {
                 if (p.resid) {
                     const f32x4 rr = *(const f32x4*)(p.resid + (long)m * p.ldr + n);
@@ -365,13 +371,15 @@ static void launch_conv(ConvArgs& a, hipStream_t stream) {
 static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w, const float* bias, float* out,
                        long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st, int sh,
                        int sw, int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr, int prec,
-                       void* stream, float out_scale = 1.0f) {
+                       void* stream, float out_scale = 1.0f, const float* act_scale = nullptr) {
     UV_CHECK_ARG(in && w && out, "uv_conv3d: null pointer");
     UV_CHECK_ARG(Cin % 32 == 0, "uv_conv3d: Cin=%d must be a multiple of 32 (pad channels with zeros)", Cin);
     UV_CHECK_ARG(Cout % 4 == 0, "uv_conv3d: Cout=%d must be a multiple of 4", Cout);
     UV_CHECK_ARG(ld_in % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0 && ld_in >= Cin, "uv_conv3d: bad leading dimensions");
     UV_CHECK_ARG(Tout > 0 && Hout > 0 && Wout > 0 && kt > 0 && kh > 0 && kw > 0, "uv_conv3d: bad geometry");
     UV_CHECK_ARG(!interleave || (Cout % 8 == 0 && !resid), "uv_conv3d: interleave needs Cout %% 8 == 0 and no residual");
+    UV_CHECK_ARG(up >= 0 && up <= 5, "uv_conv3d: up=%d (0 plain, 1 nearest-2x folded into the gather, 2..5 one output phase of it)", up);
+    UV_CHECK_ARG(up < 2 || (!resid && !interleave && sh == 1 && sw == 1 && st == 1), "uv_conv3d: an output-phase launch (up >= 2) takes no residual, interleave or stride");
     UV_CHECK_ARG((((uintptr_t)in | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)resid) & 15) == 0,
                  "uv_conv3d: pointers must be 16-byte aligned");
     ConvArgs a;
@@ -380,9 +388,10 @@ static int conv_common(const float* in, long ld_in, int Tin, int Hin, int Win, c
     a.ld_in = ld_in; a.ldo = ldo; a.ldr = ldr;
     a.Tout = Tout; a.Hout = Hout; a.Wout = Wout; a.Tin = Tin; a.Hin = Hin; a.Win = Win;
     a.Cin = Cin; a.Cout = Cout; a.kt = kt; a.kh = kh; a.kw = kw; a.st = st; a.sh = sh; a.sw = sw;
-    a.t_off = t_off; a.ph = ph; a.pw = pw; a.up = up; a.interleave = interleave;
+    a.t_off = t_off; a.ph = ph; a.pw = pw; a.up = up == 1; a.ophase = up >= 2 ? up - 2 : -1; a.interleave = interleave;
     a.M = Tout * Hout * Wout;
     a.out_scale = out_scale;
+    a.act_scale = act_scale;
     hipStream_t s = (hipStream_t)stream;
     // the large 3x3(x3) stride-1 convolutions (ResidualBlocks): LDS-halo kernel (conv3d_halo.hip), exact f32 and bf16x6
     if (uv_conv3d_halo_eligible(a, prec)) {
@@ -476,15 +485,16 @@ extern "C" int uv_split_weights_bf16x6(const float* w, void* out, long n, void* 
 
 // Same convolution, f32-grade, in THREE fp16 MFMA passes (PREC 4 above). `in` holds PRE-SPLIT activations ([C/32][32 hi | 32 lo] IEEE fp16 per
 // pixel, written by uv_vae_rms_silu with split_out = 2; ld_in counted in f32-sized elements = channels; |x| < 65 504), w_split = the
-// weights split by uv_split_weights_f16x3 with the power-of-two `w_scale`; out = acc / w_scale + bias (+ residual), f32.
+// weights split by uv_split_weights_f16x3 with the power-of-two `w_scale`; out = acc / w_scale (* *act_scale, a device scalar, when the
+// activations were split by uv_vae_split_f16 under its own power-of-two scale) + bias (+ residual), f32.
 extern "C" int uv_conv3d_f16x3(const float* in, long ld_in, int Tin, int Hin, int Win, const void* w_split, const float* bias,
                                float* out, long ldo, int Tout, int Hout, int Wout, int Cin, int Cout, int kt, int kh, int kw, int st,
                                int sh, int sw, int t_off, int ph, int pw, int up, int interleave, const float* resid, long ldr,
-                               float w_scale, void* stream) {
+                               float w_scale, const float* act_scale, void* stream) {
     int ex = 0;
     UV_CHECK_ARG(w_scale > 0.f && frexpf(w_scale, &ex) == 0.5f, "uv_conv3d_f16x3: w_scale=%g must be a power of two", (double)w_scale);
     return conv_common(in, ld_in, Tin, Hin, Win, w_split, bias, out, ldo, Tout, Hout, Wout, Cin, Cout, kt, kh, kw, st, sh, sw, t_off,
-                       ph, pw, up, interleave, resid, ldr, 4, stream, 1.0f / w_scale);
+                       ph, pw, up, interleave, resid, ldr, 4, stream, 1.0f / w_scale, act_scale);
 }
 
 // w [rows][K] f32 (K % 32 == 0) -> [rows][K/32][32 hi | 32 lo] IEEE fp16 with hi = fp16(w * scale), lo = fp16(w * scale - hi); scale is a

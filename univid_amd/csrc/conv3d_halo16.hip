@@ -157,6 +157,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     // ---- epilogue: exact power-of-two descale, bias, optional residual, f32 store
+    const float out_scale = p.act_scale ? p.out_scale * *p.act_scale : p.out_scale;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int py = wm * 2 + (j >> 1), px = (j & 1) * 16 + frow;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (n >= p.Cout) continue;
             f32x4 v = acc[i][j];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+            for (int e = 0; e < 4; ++e) v[e] *= out_scale;
             if (p.bias) {
                 const f32x4 b = *(const f32x4*)(p.bias + n);
 #pragma unroll

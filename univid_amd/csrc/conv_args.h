@@ -14,6 +14,9 @@ struct ConvArgs {
     int Tout, Hout, Wout, Tin, Hin, Win;
     int Cin, Cout, kt, kh, kw, st, sh, sw, t_off, ph, pw, up, interleave;
     int M, tiles_m, tiles_n;
+    int ophase;          // -1: plain; 0..3 = (a, b) = (ophase >> 1, ophase & 1): output pixel (t, y, x) of this launch is stored at
+                         // (t, 2y + a, 2x + b) of a [Tout, 2 Hout, 2 Wout] tensor (one phase of a 2x-upsampling convolution, see uv_conv3d_f32)
+    const float* act_scale;   // f16x3: nullptr, or a device scalar the result is multiplied by as well (uv_vae_split_f16's 1 / s)
     float out_scale;     // f16x3 (PREC 4): the accumulators carry the power-of-two scale of the split weights; out = acc * out_scale + bias
 };
 
