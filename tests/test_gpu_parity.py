@@ -798,6 +798,39 @@ def test_dit_batched_forward_is_bit_identical_to_sequential():
     assert torch.equal(mixed[0], a) and torch.equal(mixed[1], s_alone)
 
 
+def test_cfg_twin_samples_share_block0_self_attention_bit_identically():
+    """A sampling step stacks the SAME latent under two prompts (textimage2video.py:380-385). Until the first cross-attention the two
+    samples' rows are identical, so block 0's self-attention half runs once and is copied (WanModel.dedup_twins): outputs must be
+    bit-identical to the full computation - t2v (one timestep) and i2v (two timesteps per sample) - fewer entry-point calls must be
+    made, and samples that only LOOK alike (equal values in two tensors, or different per-token timesteps) must not take the shortcut."""
+    from univid_amd import _lib
+    g = load_golden("dit_tiny")
+    cfg, sd, m = _tiny_model(g["seed"])
+    Lt = 256
+    x, ctx = g["x"].to(DEV), g["ctx"].to(DEV)
+    ctx2 = (ctx * 0.5).contiguous()
+    seen = []
+    orig = m.blocks[0].self_attn._self_attn
+    m.blocks[0].self_attn._self_attn = lambda h, L, grid, freqs, xr, gate, gt, batch=1, sp=None: (seen.append(batch), orig(h, L, grid, freqs, xr, gate, gt, batch, sp))[1]
+    for t in (g["t_one"].to(DEV), g["t_two"].to(DEV)):
+        tt = torch.cat([t, t])
+        with torch.no_grad():
+            m.dedup_twins = True
+            a = m([x, x], tt, [ctx, ctx2], Lt)
+            m.dedup_twins = False
+            b = m([x, x], tt, [ctx, ctx2], Lt)
+            m.dedup_twins = True
+            c = m([x, x.clone()], tt, [ctx, ctx2], Lt)                       # equal values, two tensors: not detected, full computation
+            t_other = torch.cat([t, torch.full_like(t, 123.0)])
+            d = m([x, x], t_other, [ctx, ctx2], Lt)                          # same latent, different timesteps: must not share
+            d_ref = m([x], t_other[1:], [ctx2], Lt)[0]
+        assert seen == [1, 2, 2, 2, 1], seen                                   # block 0's self-attention: once for the twins only
+        seen.clear()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and not torch.equal(a[0], a[1])
+        assert torch.equal(c[0], b[0]) and torch.equal(c[1], b[1])
+        assert torch.equal(d[0], b[0]) and torch.equal(d[1], d_ref)
+
+
 def test_context_cache_is_bit_identical_and_tracks_changes():
     """text_embedding and the blocks' cross-attention K / V^T of the context are computed once per context (they depend on
     neither latent nor timestep, model.py:170-172, 472-478): cached forwards must equal uncached ones bit for bit, an in-place

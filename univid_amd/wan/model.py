@@ -273,10 +273,12 @@ class WanAttentionBlock(nn.Module):
         self.cross_attn.prepare()
         self._prep = {"ffn0": _Prepared(self.ffn[0]), "ffn2": _Prepared(self.ffn[2])}
 
-    def _run(self, x, L, e0_rows, tid, grid, freqs, ctx, first_block, batch=1, sp=None, kv_key=None):
+    def _run(self, x, L, e0_rows, tid, grid, freqs, ctx, first_block, batch=1, sp=None, kv_key=None, twin_rows=False):
         """x: fp32 [batch*L, C] residual stream (independent samples stacked along the token axis), updated IN PLACE.
         e0_rows: fp32 [n_t, 6C]; tid int32 [batch*L] | None; ctx: bf16 [batch*Lc, C] embedded context(s); kv_key: cache key of
-        the context's cross-attention K / V^T (WanCrossAttention._context_kv), None = recompute."""
+        the context's cross-attention K / V^T (WanCrossAttention._context_kv), None = recompute.
+        twin_rows: the stacked samples enter this block with IDENTICAL rows and timesteps (the CFG pair on one latent, before its
+        first cross-attention): the self-attention half runs on sample 0 only and its result is copied to the others."""
         C = self.dim
         dev = x.device
         n_t = e0_rows.shape[0]
@@ -286,9 +288,16 @@ class WanAttentionBlock(nn.Module):
                   _lib.stream_ptr())                                                               # model.py:239
         h = torch.empty(L, C, dtype=BF16, device=dev)
         # self-attention (model.py:243-247)
-        _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=0, scale_off=C, tid=tid,
-                           round_ln=first_block)
-        self.self_attn._self_attn(h, Ls, grid, freqs, x, tab[:, 2 * C:], tid, batch, sp)
+        if twin_rows and batch > 1 and sp is None:
+            t1 = None if tid is None else tid[:Ls]
+            _lib.layernorm_mod(x[:Ls], h[:Ls], Ls, C, self.eps, mode=1, tab=tab, shift_off=0, scale_off=C, tid=t1, round_ln=first_block)
+            self.self_attn._self_attn(h[:Ls], Ls, grid, freqs, x[:Ls], tab[:, 2 * C:], t1, 1, None)
+            for b in range(1, batch):
+                x[b * Ls:(b + 1) * Ls].copy_(x[:Ls])
+        else:
+            _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=0, scale_off=C, tid=tid,
+                               round_ln=first_block)
+            self.self_attn._self_attn(h, Ls, grid, freqs, x, tab[:, 2 * C:], tid, batch, sp)
         # cross-attention (model.py:251)
         if self.cross_attn_norm:
             _lib.layernorm_mod(x, h, L, C, self.eps, mode=2, w=self.norm3.weight, b=self.norm3.bias)
@@ -460,6 +469,7 @@ class WanModel(nn.Module):
         # on around the loop: `with model.context_cached(): ...` (WanTI2V.denoise and bench.py do).
         self.cache_context = False
         self.sp = None   # SeqParallel when Ulysses sequence parallelism is enabled (enable_sequence_parallel)
+        self.dedup_twins = True   # block 0's self-attention half once for samples that enter with identical rows (the CFG pair); A/B switch
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
 
     # ---- weight preparation -------------------------------------------------------------------------------
@@ -572,7 +582,8 @@ class WanModel(nn.Module):
         text_dim]]; seq_len: int. Returns List[Tensor[C_out, F, H, W]] float32.
 
         t_rows (extension, keyword-only): the caller's own table of the DISTINCT timesteps instead of `t`:
-        `(tvals fp32 [n_t] on the device, sorted ascending, tid int32 [B*L] token -> row | None when n_t == 1)`. With it the
+        `(tvals fp32 [n_t] on the device, sorted ascending, tid int32 [B*L] token -> row | None when n_t == 1[, same: bool - every
+        sample carries the same token -> row map, which lets identical samples share block 0's self-attention half])`. With it the
         forward contains no device -> host round trip (finding the distinct values of a [B, seq_len] tensor needs one), which
         is what makes it capturable in a HIP graph (WanTI2V.denoise builds the table from the sampler's scalar timestep and
         the i2v mask). Only for equal-shape samples (one stacked group).
@@ -616,13 +627,16 @@ class WanModel(nn.Module):
             if t_rows is not None:
                 if len(groups) != 1:
                     raise ValueError("t_rows= needs samples of one shape (a single stacked group)")
-                tvals, tid = t_rows
+                tvals, tid = t_rows[0], t_rows[1]
+                twin_t = tid is None or (len(t_rows) > 2 and bool(t_rows[2]))     # third entry: every sample has the same token -> row map
                 if tid is not None and tid.numel() != B * L:
                     raise ValueError(f"t_rows: tid must hold {B * L} token -> row indices, got {tid.numel()}")
             else:
                 tb = torch.cat([t[i].to(device=dev, dtype=torch.float32).flatten()[:L] for i in idx])
                 tvals, inv = torch.unique(tb, return_inverse=True)          # device -> host sync (sizes the table)
                 tid = None if tvals.numel() == 1 else inv.to(torch.int32).contiguous()
+                # (i2v: two timesteps per sample - the samples of a twin pair must also agree token by token)
+                twin_t = tid is None or (B > 1 and bool(torch.equal(inv.view(B, L), inv[:L].expand(B, L))))
             e_rows, e0_rows = self._time_rows(tvals.contiguous())
             ctx = ctx_all[idx[0]] if B == 1 else torch.cat([ctx_all[i] for i in idx], 0)
             kv_key = None if ctx_gen is None else (ctx_gen, tuple(idx))
@@ -639,9 +653,17 @@ class WanModel(nn.Module):
             xs = torch.empty(B * n, C, dtype=torch.float32, device=dev)
             if B * n:
                 _lib.gemm_bf16(a, self._prep["patch"].w, self._prep["patch"].b, xs, EPI_F32_FROM_BF16)
+            # The CFG pair of a sampling step is the SAME latent under two prompts (textimage2video.py:380-385): until the first
+            # cross-attention the two samples' rows are identical, so block 0's self-attention half (LayerNorm, q/k/v, RoPE,
+            # attention, o-projection: 1/60 of a step's attention and projection work) is computed once and copied. Per-sample results do
+            # not depend on the stacking (tested), so the output is bit-identical. Detected, not assumed: the same tensor object for
+            # every sample of the group and the same token -> timestep map in every sample.
+            twin = (self.dedup_twins and B > 1 and par is None and all(xs_in[i] is xs_in[idx[0]] for i in idx) and
+                    (tid is None or twin_t))
             for li, blk in enumerate(self.blocks):
                 if par is None or n:
-                    blk._run(xs, n, e0_rows, tid, (Fp, Hp, Wp), fr, ctx, first_block=(li == 0), batch=B, sp=sp_arg, kv_key=kv_key)
+                    blk._run(xs, n, e0_rows, tid, (Fp, Hp, Wp), fr, ctx, first_block=(li == 0), batch=B, sp=sp_arg, kv_key=kv_key,
+                             twin_rows=(twin and li == 0))
                 else:   # a rank without tokens still takes part in the self-attention exchanges
                     blk.self_attn._self_attn_sp(xs.new_empty(0, C).to(BF16), 0, (Fp, Hp, Wp), fr, xs, None, None, B, sp_arg)
             yh = self.head._run(xs, B * n, e_rows, tid) if B * n else xs.new_empty(0, self.head.head.out_features)

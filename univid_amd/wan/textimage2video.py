@@ -118,7 +118,7 @@ class _GraphedPair:
             ctx = [context[0], context_null[0]]
             self.lat.copy_(latent)
             # eager warm-up on the capture inputs: weight preparation, context cache, scratch buffers, function attributes
-            model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid))
+            model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid, True))
             torch.cuda.synchronize(dev)
             # the graph reads the cached context tensors by address: keep them alive for as long as the graph lives, and remember
             # which context generation they belong to (a later generation means the model has dropped them from its cache)
@@ -126,7 +126,7 @@ class _GraphedPair:
             self.keep = (model._ctx_cache, [dict(b.cross_attn._kv_cache) for b in model.blocks], ctx)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.out = model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid))
+                self.out = model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid, True))
 
     def __call__(self, latent, t):
         with torch.cuda.device(self.dev):
