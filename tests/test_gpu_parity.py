@@ -2195,8 +2195,10 @@ def test_conv3d_halo_kernel_geometries(entry):
         assert_f32_close(got.permute(3, 0, 1, 2), ref.permute(3, 0, 1, 2), rtol=1e-4, atol=1e-4, name=f"halo up {entry} {T}x{H}x{W} {ci}->{co}")
         assert (got - old).abs().max() <= 1e-5 * max(1.0, float(old.abs().max()))
     # (Cout 160 / 320: the exact-f32 kernel's 160-wide output tile - the encoder's stages; the bf16x6 entry keeps the gather kernel there)
+    # (Cout 12: the decoder's head convolution - the f16x3 entry has a narrow-output halo kernel for it, the others keep the gather kernel)
     for (T, H, W, ci, co, kt) in ((3, 19, 23, 64, 128, 3), (2, 8, 32, 32, 256, 3), (2, 40, 70, 64, 128, 3), (4, 16, 64, 96, 128, 1),
-                                  (2, 19, 23, 64, 160, 3), (2, 16, 33, 32, 320, 3)):
+                                  (2, 19, 23, 64, 160, 3), (2, 16, 33, 32, 320, 3), (3, 19, 40, 64, 12, 3), (2, 8, 32, 32, 16, 1),
+                                  (2, 17, 40, 128, 128, 3), (3, 16, 64, 64, 256, 1)):
         x = torch.randn(1, ci, T, H, W, generator=g)
         w, b = torch.randn(co, ci, kt, 3, 3, generator=g) * 0.05, torch.randn(co, generator=g)
         res = torch.randn(T, H, W, co, generator=g).to(DEV)
