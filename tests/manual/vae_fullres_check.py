@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from oracle import wan_vae
 from univid_amd.wan.vae2_2 import Wan2_2_VAE
 dev = "cuda"
-vae = Wan2_2_VAE(device=dev, seed=2)
+vae = Wan2_2_VAE(device=dev, seed=2, precision="fp32")
 sd = {k: v.detach() for k, v in vae.model.state_dict().items()}
 ora = wan_vae.WanVAE(sd, wan_vae.FULL_CFG)
 scale = [t.to(dev) for t in wan_vae.scale_tensors()]

@@ -1,6 +1,7 @@
-"""End-to-end generation time at the bench size (developer tool): WanTI2V.t2v / i2v with the production model sizes (30-block TI2V-5B
-DiT, full-width VAE, random-init weights, synthetic prompt embeddings): 50 UniPC steps with CFG + VAE decode of the 49-frame 704x1280
-clip, per stage, for the exact-f32 VAE and the f32-grade bf16x6 mode."""
+"""End-to-end generation time (developer tool): WanTI2V.t2v / i2v with the production model sizes (30-block TI2V-5B DiT, full-width VAE,
+random-init weights, synthetic prompt embeddings): 50 UniPC steps with CFG + VAE decode, per stage, for the exact-f32 VAE and the
+f32-grade bf16x6 / f16x3 modes - at the bench size (49 frames of 704 x 1280) and at UniVid's own default workload (121 frames of
+704 x 1280, inference.py:48-50).   env: STEPS (50), FRAMES ("49,121"), PRECS ("fp32,bf16x6,f16x3")"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from univid_amd import _lib
@@ -25,18 +26,22 @@ def clock(fn):
     return r, time.perf_counter() - t0
 
 
-for prec in ("fp32", "bf16x6"):
-    vae = Wan2_2_VAE(device=dev, seed=0, precision=prec)
-    pipe = WanTI2V(model=m, vae=vae, device=dev)
-    with torch.no_grad():
-        pipe.t2v("", size=(1280, 704), frame_num=49, sampling_steps=2, seed=7, prompt_embeds=pe, negative_prompt_embeds=ne)   # warm-up
-        lat, t_den = clock(lambda: pipe.t2v("", size=(1280, 704), frame_num=49, sampling_steps=steps, seed=7, prompt_embeds=pe,
-                                            negative_prompt_embeds=ne, decode=False))
-        vid, t_dec = clock(lambda: vae.decode([lat])[0])
-        img = vid[:, 0].clamp(-1, 1).contiguous()
-        _, t_i2v = clock(lambda: pipe.i2v("", img, max_area=704 * 1280, frame_num=49, sampling_steps=steps, seed=3, prompt_embeds=pe,
-                                          negative_prompt_embeds=ne))
-    print(f"VAE {prec:7s}: t2v {steps} steps {t_den:6.2f} s ({t_den / steps * 1e3:.1f} ms/step) + decode {t_dec:5.2f} s = {t_den + t_dec:6.2f} s per "
-          f"49-frame 704x1280 clip; i2v (encode 1 frame + {steps} steps + decode) {t_i2v:6.2f} s; finite {bool(torch.isfinite(vid).all())}", flush=True)
-    del vae, pipe
-    torch.cuda.empty_cache()
+frames = [int(f) for f in os.environ.get("FRAMES", "49,121").split(",")]
+precs = os.environ.get("PRECS", "fp32,bf16x6,f16x3").split(",")
+for F in frames:
+    for prec in precs:
+        vae = Wan2_2_VAE(device=dev, seed=0, precision=prec)
+        pipe = WanTI2V(model=m, vae=vae, device=dev)
+        with torch.no_grad():
+            pipe.t2v("", size=(1280, 704), frame_num=F, sampling_steps=2, seed=7, prompt_embeds=pe, negative_prompt_embeds=ne)   # warm-up
+            lat, t_den = clock(lambda: pipe.t2v("", size=(1280, 704), frame_num=F, sampling_steps=steps, seed=7, prompt_embeds=pe,
+                                                negative_prompt_embeds=ne, decode=False))
+            vid, t_dec = clock(lambda: vae.decode([lat])[0])
+            img = vid[:, 0].clamp(-1, 1).contiguous()
+            _, t_i2v = clock(lambda: pipe.i2v("", img, max_area=704 * 1280, frame_num=F, sampling_steps=steps, seed=3, prompt_embeds=pe,
+                                              negative_prompt_embeds=ne))
+        print(f"{F:3d} frames, VAE {prec:7s}: t2v {steps} steps {t_den:6.2f} s ({t_den / steps * 1e3:.1f} ms/step) + decode {t_dec:5.2f} s = "
+              f"{t_den + t_dec:6.2f} s per {F}-frame 704x1280 clip (latent {list(lat.shape)}); i2v (encode 1 frame + {steps} steps + decode) "
+              f"{t_i2v:6.2f} s; finite {bool(torch.isfinite(vid).all())}", flush=True)
+        del vae, pipe, vid, lat
+        torch.cuda.empty_cache()
