@@ -372,7 +372,15 @@ class _Engine:
         """ResidualBlock.forward vae2_2.py:214-235."""
         T, H, W, C = x.shape
         res = blk.residual
-        h = x if isinstance(blk.shortcut, nn.Identity) else self._pointwise(self.ops[blk.shortcut], x)
+        if isinstance(blk.shortcut, nn.Identity):
+            h = x
+        elif self.precision == "f16x3" and C % 32 == 0 and blk.out_dim % 4 == 0 and x.is_contiguous() and T * H * W >= 65536:
+            # the 1x1x1 shortcut of the channel-changing blocks (1024 -> 512, 512 -> 256 on 16 large frames: 8 ms each on the exact-f32
+            # GEMM) as a three-pass fp16 product too: raw rows, so under the device-found per-tensor scale (uv_vae_split_f16)
+            xs, sc = self._split16(x)
+            h = self._conv(self.ops[blk.shortcut], xs, T, H, W, T, H, W, in_split=2, act_scale=sc)
+        else:
+            h = self._pointwise(self.ops[blk.shortcut], x)
         sp1, sp2 = self.split_fmt(res[0], C, blk.out_dim), self.split_fmt(res[3], blk.out_dim, blk.out_dim)
         y = self.causal_conv(res[2], lambda dst: self._rms_silu(x, res[0].gamma, dst, split=sp1), T, H, W, in_split=sp1)
         return self.causal_conv(res[6], lambda dst: self._rms_silu(y, res[3].gamma, dst, split=sp2), T, H, W, resid=h, in_split=sp2)
