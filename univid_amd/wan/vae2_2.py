@@ -374,7 +374,7 @@ class _Engine:
         res = blk.residual
         if isinstance(blk.shortcut, nn.Identity):
             h = x
-        elif self.precision == "f16x3" and C % 32 == 0 and blk.out_dim % 4 == 0 and x.is_contiguous() and T * H * W >= 65536:
+        elif self.precision == "f16x3" and C % 32 == 0 and blk.out_dim % 4 == 0 and x.is_contiguous() and H * W >= 16384:     # (per-FRAME size: the choice never depends on the pass length)
             # the 1x1x1 shortcut of the channel-changing blocks (1024 -> 512, 512 -> 256 on 16 large frames: 8 ms each on the exact-f32
             # GEMM) as a three-pass fp16 product too: raw rows, so under the device-found per-tensor scale (uv_vae_split_f16)
             xs, sc = self._split16(x)
