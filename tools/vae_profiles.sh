@@ -1,5 +1,5 @@
 # Runs ON the GPU box: rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of a full-size VAE encode + decode.
-# usage: vae_profiles.sh [fp32|bf16x6] [both|decode|encode]
+# usage: vae_profiles.sh [fp32|bf16x6|f16x3] [both|decode|encode]
 PREC=${1:-fp32}; WHAT=${2:-both}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
