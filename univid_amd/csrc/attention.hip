@@ -918,6 +918,13 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         tile(t, F{}, T_{}, P0{});
         tile(t + 1, F{}, T_{}, P1{});
     }
+    // Tail: up to five compile-time instantiations behind this if / else chain. hipcc allocates registers across the chain and SPILLS
+    // there (315 registers, 408 bytes of scratch per lane; none inside the loop above): ~150 MB of scratch writes per batch-2 launch at
+    // L = 11 440, which is half of what rocprofv3's WRITE_SIZE reports for this kernel (287 640 KB against 137 280 KB of output). Round 4
+    // replaced the chain by ONE generic tile (run-time parity / next-tile / mask decisions) in a loop of its own: 1 spilled register,
+    // bit-identical - and SLOWER in a same-process A/B of the two libraries (tools/attn_so_ab.py: 2.763 against 2.731 ms; the
+    // cross-attention kernel, 2 of whose 8 tiles run in its tail, 178.4 against 172.4 us). The spills go to L2 and cost less than the
+    // generic tile's run-time addressing; the specialised chain stays.
     if (t + 1 < nt_full) {
         tile(t, F{}, T_{}, P0{});
         tile(t + 1, F{}, F{}, P1{});
