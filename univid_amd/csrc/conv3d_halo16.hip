@@ -24,17 +24,20 @@
 
 typedef __attribute__((address_space(3))) void lds_void_g;
 
-template <int BN = 128>
+// BN = output channels per workgroup: 128 with two-tap steps (four 16-KiB weight tiles), or 160 for the encoder's 160 / 320-channel stages with
+// ONE tap per step (two 20-KiB tiles: 126 KiB of LDS; two-tap steps would need 166 KiB) - the step length was measured not to matter (§9 round 4).
+template <int BN = 128, int TAPS = 2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3d_halo_f16_kernel(ConvArgs p) {
     constexpr int TW = 32, TH = 8, HW_ = TW + 2, NHP = (TH + 2) * HW_;       // 340 halo pixels
     constexpr int NW = 8, TM = 4, TN = BN / 32;
     constexpr int H_PIECES = (NHP + 7) / 8;                                  // 43 one-KiB pieces (8 pixels x 128 B)
     constexpr int HALO_BYTES = H_PIECES * 1024;                              // 44 032
     constexpr int H_INSTR = (H_PIECES + NW - 1) / NW;                        // 6 (waves 0..2) / 5
-    constexpr int W_BYTES = BN * 128, W_INSTR = W_BYTES / 1024 / NW;         // 16 KiB, 2 pieces per wave
+    constexpr int W_BYTES = BN * 128, W_PIECES = W_BYTES / 1024, W_INSTR = (W_PIECES + NW - 1) / NW;   // 16 / 20 KiB: 2 / 2-3 pieces per wave
+    static_assert(BN == 128 || BN == 160, "output-channel tile");
     static_assert(H_INSTR <= 6, "one halo piece per tap during taps 1..6");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const wbuf = smem + 2 * HALO_BYTES;         // four weight tiles: two steps x two taps
+    char* const wbuf = smem + 2 * HALO_BYTES;         // 2 * TAPS weight tiles: two steps x TAPS taps
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +90,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int koff = ((dt * 9 + tap) * ncb + cb) * 32;                   // k order of the weight matrix: tap-major, channels minor
 #pragma unroll
         for (int i = 0; i < W_INSTR; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(w_src[i] + koff), (lds_void_g*)(wbuf + wb * W_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
+            if (W_PIECES % NW == 0 || i * NW + wave < W_PIECES)
+                __builtin_amdgcn_global_load_lds((const void*)(w_src[i] + koff), (lds_void_g*)(wbuf + wb * W_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[TN][TM];
@@ -138,11 +142,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // consecutive channel groups form one unrolled sequence of 18 taps = 9 steps (the host sends only even group counts here); the
     // weights of the NEXT step (2 x 16 KiB) and, during taps 1..6 of a group, one halo piece of the next group are in flight behind
     // the 96 MFMAs of a step.
-    auto stage_w2 = [&](int g, int q, int sb) __attribute__((always_inline)) {      // the two taps q, q + 1 of the 18-tap sequence starting at group g
+    auto stage_w2 = [&](int g, int q, int sb) __attribute__((always_inline)) {      // the TAPS taps q .. of the 9 * TAPS-tap sequence starting at group g
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < TAPS; ++u) {
             const int qq = q + u, gg = g + qq / 9;
-            if (gg < ngroups) stage_w(gg, qq % 9, sb * 2 + u);
+            if (gg < ngroups) stage_w(gg, qq % 9, sb * TAPS + u);
         }
     };
 #pragma unroll
@@ -151,22 +155,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int sb = 0;
-    for (int g = 0; g < ngroups; g += 2) {
+    for (int g = 0; g < ngroups; g += TAPS) {
 #pragma unroll
         for (int st = 0; st < 9; ++st) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < TAPS; ++u) {
                 // halo pieces of the group after each tap's own group, piece `tap - 1` at taps 1..6: the image they go to was last
                 // read by tap 8 of the group BEFORE this one, which shares its step with this group's tap 0 when the group is the
                 // second of the pair - so nothing is issued at tap 0, and every piece lands behind a barrier that follows that read
-                const int q = 2 * st + u, gg = g + q / 9, tap = q % 9;
+                const int q = TAPS * st + u, gg = g + q / 9, tap = q % 9;
                 if (tap >= 1 && tap - 1 < H_INSTR && gg + 1 < ngroups) stage_halo_piece(gg + 1, tap - 1, (gg + 1) & 1);
             }
-            stage_w2(g, 2 * st + 2, sb ^ 1);     // (crosses into the next pair of groups at st = 8)
+            stage_w2(g, TAPS * st + TAPS, sb ^ 1);     // (crosses into the next block of groups at st = 8)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int q = 2 * st + u, gg = g + q / 9, tap = q % 9;
-                compute(tap, wbuf + (sb * 2 + u) * W_BYTES, smem + (gg & 1) * HALO_BYTES);
+            for (int u = 0; u < TAPS; ++u) {
+                const int q = TAPS * st + u, gg = g + q / 9, tap = q % 9;
+                compute(tap, wbuf + (sb * TAPS + u) * W_BYTES, smem + (gg & 1) * HALO_BYTES);
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();
@@ -340,8 +344,10 @@ bool uv_conv3d_halo16_eligible(const ConvArgs& a) {
         const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
         return !a.up && a.Cout % 4 == 0 && (force == 1 || 4 * tiles >= uv_num_cus());
     }
-    if (a.Cout % 128 != 0 || ((a.kt * (a.Cin >> 5)) & 1)) return false;       // (the two-tap steps pair the channel groups: even counts only)
-    const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * (a.Cout / 128);
+    // 128-wide output tiles (two-tap steps pair the channel groups: even counts only), or whole 160-wide ones (the encoder's 160 / 320-channel stages)
+    const int bn = a.Cout % 128 == 0 ? 128 : a.Cout % 160 == 0 ? 160 : 0;
+    if (bn == 0 || (bn == 128 && ((a.kt * (a.Cin >> 5)) & 1))) return false;
+    const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * (a.Cout / bn);
     return force == 1 || 4 * tiles >= uv_num_cus();
 }
 
@@ -354,8 +360,15 @@ int uv_launch_conv3d_halo16(ConvArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(conv3d_halo_f16_n16_kernel, dim3(a.tiles_m), dim3(512), lds, stream, a);
         return 0;
     }
-    a.tiles_n = a.Cout / 128;
     a.tiles_m = a.Tout * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
+    if (a.Cout % 128 != 0) {
+        a.tiles_n = a.Cout / 160;
+        const size_t lds160 = 2 * 43 * 1024 + 2 * 160 * 128;                 // two halo images + two 20-KiB weight tiles = 126 KiB
+        UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)conv3d_halo_f16_kernel<160, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds160));
+        hipLaunchKernelGGL((conv3d_halo_f16_kernel<160, 1>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds160, stream, a);
+        return 0;
+    }
+    a.tiles_n = a.Cout / 128;
     const size_t lds = 2 * 43 * 1024 + 4 * 128 * 128;                        // two halo images + four weight tiles = 150 KiB
     UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)conv3d_halo_f16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((conv3d_halo_f16_kernel<128>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
