@@ -29,6 +29,9 @@
 //   * independent samples are one launch: q/k/out rows and V^T COLUMNS stacked per sample.
 // Template parameters of flash_attn_fwd_kernel: D head_dim (128 / 64), SGB fragment reads scheduled 6 ahead of their MFMA, F16 IEEE fp16 operands.
 #include "attn_args.h"
+#ifndef UV_ATTN_PROBE
+#define UV_ATTN_PROBE 0      // 1 / 2: timing-only LDS-read probes of flash_attn_fwd12_kernel, built only by tools/diag/build_attn_probe.py
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -792,6 +795,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+#if UV_ATTN_PROBE
+    bf16x8 kf_keep = qf[0], vf_keep = qf[1];      // timing-only probes (see the tile body): never in the product build
+#endif
 
     const int nt = (p.Lk + UV_ATT_KV - 1) / UV_ATT_KV;
     const int nt_full = p.Lk / UV_ATT_KV;
@@ -839,7 +845,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
+#if UV_ATTN_PROBE == 1      // timing-only probe (tools/diag/build_attn_probe.py; WRONG results): half of the fragment reads skipped, the skipped fragment = a copy of the previous one
+                bf16x8 kf;
+                if (kk & 1) kf = kf_keep; else kf = *(lds_frag_p)(kaddr[kk] + PAR * K_BYTES + T * 32 * KROW);
+                kf_keep = kf;
+#elif UV_ATTN_PROBE == 2    // timing-only probe: every read still issued and waited for, the odd fragments then REPLACED by a copy of the previous one (same operand data as probe 1)
+                bf16x8 kf = *(lds_frag_p)(kaddr[kk] + PAR * K_BYTES + T * 32 * KROW);
+                if (kk & 1) { asm volatile("" :: "v"(kf)); kf = kf_keep; }
+                kf_keep = kf;
+#else
                 const bf16x8 kf = *(lds_frag_p)(kaddr[kk] + PAR * K_BYTES + T * 32 * KROW);
+#endif
                 sacc = mfma_32x32x16<false>(kf, qf[kk], sacc);
             }
             __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
@@ -893,7 +909,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int d = 0; d < ND; ++d)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
+#if UV_ATTN_PROBE == 1
+                    bf16x8 vf;
+                    if (s2 & 1) vf = vf_keep; else vf = *(lds_frag_p)(vaddr[T][s2] + PAR * V_BYTES + d * 32 * 128);
+                    vf_keep = vf;
+#elif UV_ATTN_PROBE == 2
+                    bf16x8 vf = *(lds_frag_p)(vaddr[T][s2] + PAR * V_BYTES + d * 32 * 128);
+                    if (s2 & 1) { asm volatile("" :: "v"(vf)); vf = vf_keep; }
+                    vf_keep = vf;
+#else
                     const bf16x8 vf = *(lds_frag_p)(vaddr[T][s2] + PAR * V_BYTES + d * 32 * 128);
+#endif
                     oacc[d] = mfma_32x32x16<false>(vf, pf[s2], oacc[d]);
                 }
             __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 1);
