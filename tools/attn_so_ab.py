@@ -4,9 +4,12 @@
 import ctypes, math, os, statistics, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from univid_amd import _lib
-_lib.init()
-libs = {"tree": ctypes.CDLL(_lib.LIB_PATH), "other": ctypes.CDLL(os.path.abspath(sys.argv[1]))}
+torch.cuda.init()
+TREE_LIB = os.path.join(ROOT, "univid_amd", "libunivid_hip.so")
+# RTLD_DEEPBIND: the two libraries export the SAME symbols (kernel host stubs included); without it the second library's internal references
+# resolve to the first one's globally visible definitions and both "builds" launch the same kernels (found the hard way in round 4)
+_mode = os.RTLD_NOW | os.RTLD_LOCAL | os.RTLD_DEEPBIND
+libs = {"tree": ctypes.CDLL(TREE_LIB, mode=_mode), "other": ctypes.CDLL(os.path.abspath(sys.argv[1]), mode=_mode)}
 P, L_, I_ = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
 for lib in libs.values():
     lib.uv_init()
@@ -26,8 +29,8 @@ for (Lq, Lk, B, n) in ((11440, 11440, 2, 5), (11440, 512, 2, 20), (27280, 27280,
         rc = libs[name].uv_flash_attn_bf16(q.data_ptr(), C, k.data_ptr(), C, vt.data_ptr(), vt.stride(0), o.data_ptr(), C, B, Lq, Lk, H, D, 1 / math.sqrt(D), st)
         assert rc == 0
     res = {n_: [] for n_ in libs}
-    for r in range(4):
-        for name in libs:
+    for r in range(6):
+        for name in (list(libs) if r % 2 == 0 else list(libs)[::-1]):      # alternate the order: the second of a pair measured 0.3-2.5 % faster
             run(name); run(name)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()

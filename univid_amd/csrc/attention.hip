@@ -493,10 +493,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // MFMAs at 168 registers per wave. The reference maximum is therefore reconsidered per half.
     // NEXT: 1 = tile t+1 is a full one, 0 = decide at run time (ragged or none); PAR = t & 1 (compile-time: the K buffer
     // offsets become instruction immediates)
+    // PAR = -1: the GENERIC form of the tail tiles (parity, "is the next tile full" and "is this the ragged tile" decided at run time).
+    // Until round 4 the tail was five compile-time instantiations behind an if / else chain; hipcc allocated registers across that chain
+    // and SPILLED 380 of them to scratch (444 bytes per lane; none in the main loop) - and 2 of the cross-attention's 8 tiles ran there.
+    // One generic instantiation in a loop of its own keeps the tail at the main loop's register footprint (8 spilled registers, none
+    // in a loop): the cross-attention launch 193.9 -> 165.8 us (two builds of the library in one process, tools/attn_so_ab.py), bit-identical.
     auto tile = [&](int t, auto masked_tag, auto next_tag, auto par_tag) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        constexpr bool NEXT_FULL = decltype(next_tag)::value;
-        constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool DYN = decltype(par_tag)::value < 0;
+        constexpr bool MASKED_C = decltype(masked_tag)::value;
+        constexpr bool NEXT_FULL = decltype(next_tag)::value && !DYN;
+        const int PAR = DYN ? (t & 1) : decltype(par_tag)::value;
+        const bool MASKED = DYN ? (t >= nt_full) : MASKED_C;
         const int kv0 = t * UV_ATT_KV;
         fetch_v(vbase);                                  // V^T(t): the buffer was released by the barrier that ended tile t-1
         vbase += 2 * UV_ATT_KV;
@@ -604,17 +611,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         tile(t, F{}, T_{}, P0{});
         tile(t + 1, F{}, T_{}, P1{});
     }
-    // 0, 1 or 2 full tiles left (t is even)
-    if (t + 1 < nt_full) {
-        tile(t, F{}, T_{}, P0{});
-        tile(t + 1, F{}, F{}, P1{});
-    } else if (t < nt_full) {
-        tile(t, F{}, F{}, P0{});
-    }
-    if (nt_full < nt) {
-        if (nt_full & 1) tile(nt_full, T_{}, F{}, P1{});
-        else tile(nt_full, T_{}, F{}, P0{});
-    }
+    // the last one or two full tiles and the ragged tile: the generic form, in a loop of its own
+    for (; t < nt; ++t) tile(t, F{}, F{}, std::integral_constant<int, -1>{});
 
     UV_TL(vb, 2);
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -825,10 +823,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         return;
     }
 
+    // PAR = -1: the generic form of the tail tiles (see flash_attn_fwd3_kernel). Here the if / else chain of five instantiations spilled
+    // 315 registers (408 bytes of scratch per lane) in the last two or three tiles of every workgroup: ~150 MB of scratch writes per
+    // batch-2 launch at L = 11 440 - HALF of what rocprofv3's WRITE_SIZE reported for this kernel (287 640 KB against 137 280 KB of
+    // output; tools/diag/attn_write_probe.*). With the generic tail: 1 spilled register, the launch time unchanged (2.740 against 2.742 ms;
+    // three tiles of 179 per workgroup), bit-identical.
     auto tile = [&](int t, auto masked_tag, auto next_tag, auto par_tag) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        constexpr bool NEXT_FULL = decltype(next_tag)::value;
-        constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool DYN = decltype(par_tag)::value < 0;
+        constexpr bool MASKED_C = decltype(masked_tag)::value;
+        constexpr bool NEXT_FULL = decltype(next_tag)::value && !DYN;
+        const int PAR = DYN ? (t & 1) : decltype(par_tag)::value;
+        const bool MASKED = DYN ? (t >= nt_full) : MASKED_C;
         const int kv0 = t * UV_ATT_KV;
         vbase += 2 * UV_ATT_KV;
         kbase += kstep;
@@ -944,23 +949,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         tile(t, F{}, T_{}, P0{});
         tile(t + 1, F{}, T_{}, P1{});
     }
-    // Tail: up to five compile-time instantiations behind this if / else chain. hipcc allocates registers across the chain and SPILLS
-    // there (315 registers, 408 bytes of scratch per lane; none inside the loop above): ~150 MB of scratch writes per batch-2 launch at
-    // L = 11 440, which is half of what rocprofv3's WRITE_SIZE reports for this kernel (287 640 KB against 137 280 KB of output). Round 4
-    // replaced the chain by ONE generic tile (run-time parity / next-tile / mask decisions) in a loop of its own: 1 spilled register,
-    // bit-identical - and SLOWER in a same-process A/B of the two libraries (tools/attn_so_ab.py: 2.763 against 2.731 ms; the
-    // cross-attention kernel, 2 of whose 8 tiles run in its tail, 178.4 against 172.4 us). The spills go to L2 and cost less than the
-    // generic tile's run-time addressing; the specialised chain stays.
-    if (t + 1 < nt_full) {
-        tile(t, F{}, T_{}, P0{});
-        tile(t + 1, F{}, F{}, P1{});
-    } else if (t < nt_full) {
-        tile(t, F{}, F{}, P0{});
-    }
-    if (nt_full < nt) {
-        if (nt_full & 1) tile(nt_full, T_{}, F{}, P1{});
-        else tile(nt_full, T_{}, F{}, P0{});
-    }
+    // the last one or two full tiles and the ragged tile: the generic form, in a loop of its own
+    for (; t < nt; ++t) tile(t, F{}, F{}, std::integral_constant<int, -1>{});
 
     UV_TL(blockIdx.x, 2);
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
