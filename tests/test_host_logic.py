@@ -480,3 +480,44 @@ def test_pw4_attention_isa_audit():
         text = open(out).read()
     assert not findings, findings[:5]
     assert "scratch_" not in text.split("flash_attn_pw4_kernel")[1].split(".amdhsa_")[0], "the pw4 kernel must not touch scratch memory"
+
+
+def test_upsample_phase_weights_reproduce_the_3x3_convolution_on_cpu():
+    """Host logic of the round-4 phase decomposition (univid_amd/wan/vae2_2.py: _ConvOp.phases): Resample's "nearest-exact 2x + Conv2d 3x3"
+    (vae2_2.py:86-96, 153-155) equals four 2x2 convolutions of the SOURCE image - output pixels (2y + a, 2x + b) from the taps' pre-summed
+    weights with padding (1 - a, 1 - b) - checked here with plain torch ops on the CPU, incl. the zero padding at all four borders."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from univid_amd.wan.vae2_2 import _ConvOp
+    torch.manual_seed(5)
+    conv = nn.Conv2d(40, 24, 3, padding=1).double()
+    op = _ConvOp(conv, is2d=True)                      # weights re-laid as [Cout, 3, 3, Cin_pad] (Cin padded 40 -> 64)
+    x = torch.randn(2, 40, 5, 7, dtype=torch.float64)
+    up = F.interpolate(x, scale_factor=2.0, mode="nearest-exact")
+    ref = conv(up)
+    out = torch.zeros(2, 24, 10, 14, dtype=torch.float64)
+    for k, ph in enumerate(op.phases()):
+        a, b = k >> 1, k & 1
+        assert (ph.kt, ph.kh, ph.kw, ph.cout, ph.cin_pad) == (1, 2, 2, 24, 64)
+        w = ph.w.view(24, 2, 2, 64)[..., :40].permute(0, 3, 1, 2).double()      # [Cout, Cin, 2, 2]
+        # rows y + i - (1 - a), i in {0, 1}: pad (1 - a) rows on top and a rows at the bottom (the kernel's out-of-range taps read zero)
+        xp = F.pad(x, (1 - b, b, 1 - a, a))
+        out[:, :, a::2, b::2] = F.conv2d(xp, w, conv.bias)
+    # the phase weights are the f32 roundings of fp64 sums of f32-rounded taps: compare against the convolution with THOSE taps
+    conv32 = nn.Conv2d(40, 24, 3, padding=1).double()
+    conv32.weight.data = conv.weight.data.float().double()
+    conv32.bias.data = conv.bias.data.float().double()
+    ref32 = conv32(up)
+    assert (out - ref32).abs().max() <= 1e-6 * ref32.abs().max(), float((out - ref32).abs().max())
+    assert (out - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+def test_f16x3_weight_scale_rule():
+    """f16_weight_scale: a power of two, max |w| * scale in [2^13, 2^14) for every magnitude, 1.0 for zero / non-finite tensors."""
+    import math
+    from univid_amd.wan.vae2_2 import f16_weight_scale
+    for mx in (1e-8, 3.1e-4, 0.02, 0.5, 1.0, 1.9999, 2.0, 77.0, 6.0e4, 1e9):
+        sc = f16_weight_scale(mx)
+        assert math.frexp(sc)[0] == 0.5 and 2.0 ** 13 <= mx * sc < 2.0 ** 14, (mx, sc)
+    assert f16_weight_scale(0.0) == 1.0 and f16_weight_scale(float("inf")) == 1.0 and f16_weight_scale(float("nan")) == 1.0
+

@@ -154,6 +154,15 @@ def _pad32(c):
     return (c + 31) // 32 * 32
 
 
+def f16_weight_scale(max_abs):
+    """Power of two that puts the largest weight magnitude of a convolution into [2^13, 2^14) for the f16x3 split (uv_split_weights_f16x3):
+    far below fp16's 65 504, and the lo pieces (<= 2^-11 of their hi piece) of all but the smallest weights stay normal fp16 numbers
+    (>= 2^-14). 1.0 for an all-zero or non-finite tensor."""
+    if not (max_abs > 0 and math.isfinite(max_abs)):
+        return 1.0
+    return 2.0 ** (13 - math.floor(math.log2(max_abs)))
+
+
 class _ConvOp:
     """One convolution: channels-last weight [Cout, taps * Cin_pad] and its input ring."""
 
@@ -193,8 +202,7 @@ class _ConvOp:
         max |w| into [2^13, 2^14): all but the smallest weights then have NORMAL lo pieces (fp16 subnormals start below 2^-14), and
         65 504 is far away. The kernel undoes the scale exactly in its epilogue."""
         if self.w_split_f16 is None:
-            mx = float(self.w.abs().max())
-            scale = 2.0 ** (13 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+            scale = f16_weight_scale(float(self.w.abs().max()))
             buf = torch.empty(self.w.numel() * 2, dtype=torch.float16, device=self.w.device)
             _lib.call("uv_split_weights_f16x3", _lib.ptr(self.w), _lib.ptr(buf), self.w.numel(), float(scale), _lib.stream_ptr())
             self.w_split_f16 = (buf, float(scale))
