@@ -391,6 +391,9 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the CFG pair's forward from a captured HIP graph (what "
+                    "WanTI2V.denoise does for the plain single-process loop): same kernels, same order, bit-identical; the host then issues a handful "
+                    "of launches per step instead of ~500. auto = as WanTI2V.denoise decides")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--no-default-shape", action="store_true", help="skip the (untimed-region) 3-step run at UniVid's default 121-frame latent (L = 27 280)")
     ap.add_argument("--no-stress-shape", action="store_true", help="skip the (untimed-region) 2-block probe at the literal 49x90x160 latent")
@@ -468,7 +471,13 @@ def main():
     seq_len = L_TOKENS
     assert args.warmup + args.steps <= len(timesteps)
 
+    from univid_amd.wan.textimage2video import _GraphedPair, graph_by_default
+    use_graph = (args.graph == "on" or (args.graph == "auto" and graph_by_default(seq_len))) and cfgp is None and not use_sp
+    runner = None
+
     def forward_pair(i, lat):
+        if runner is not None:
+            return runner(lat, float(timesteps[i]))
         tvec = torch.full((1, seq_len), float(timesteps[i]), device=device)
         # exactly what WanTI2V.denoise does per timestep: the CFG pair as one stacked pass (bit-identical per sample)
         if cfgp is not None:
@@ -486,6 +495,8 @@ def main():
 
     # the loop owns its (loop-constant) context tensors, as WanTI2V.denoise does: step-constant context work once per context
     with torch.no_grad(), model.context_cached():
+        if use_graph:      # one capture, replayed by every step (WanTI2V.denoise's runner)
+            runner = _GraphedPair(model, latent, ctx, ctx_null, seq_len, None)
         for i in range(args.warmup):
             latent = one_step(i, latent)
         barrier()
@@ -504,6 +515,7 @@ def main():
         # self-attention launches of a step, each in its real place between the block's other kernels.
         _lib.PROFILE = {"uv_flash_attn_bf16": []}
         _lib.PROFILE_ALL = bool(args.kernel_times)
+        runner = None      # (eager launches: HIP events around individual kernels cannot be recorded inside a graph replay)
         forward_pair(min(args.warmup + args.steps, len(timesteps) - 1), latent)      # the step's two forwards (the sampler update launches no attention)
         barrier()
         prof = _lib.PROFILE
@@ -573,6 +585,7 @@ def main():
             # host side of a step (at N ranks on one host, N x this against the host's cores is the scaling risk)
             "host_cpu_ms_per_step": round((cpu1 - cpu0) / args.steps * 1e3, 3),
             "launches_per_step": round((calls1 - calls0) / args.steps, 1),
+            "graph": bool(use_graph),
             "host_note": "process CPU time (user + system, all threads of this rank) spent issuing one step's launches, and C-ABI entry-point calls per step",
         }
         if args.kernel_times:
