@@ -15,7 +15,7 @@ b.build(verbose=False)
 objs = [os.path.join(b.OBJDIR, os.path.basename(s)[:-4] + ".o") for s in b.sources() if not s.endswith("attention.hip")]
 for n in (1, 2):
     o = os.path.join(HERE, f"attention_probe{n}.o")
-    subprocess.check_call([b._hipcc(), *b.FLAGS, f"-DUV_ATTN_PROBE={n}", "-c", os.path.join(b.CSRC, "attention.hip"), "-o", o])
+    subprocess.check_call([b._hipcc(), *b.FLAGS, *b.FILE_FLAGS.get("attention.hip", []), f"-DUV_ATTN_PROBE={n}", "-c", os.path.join(b.CSRC, "attention.hip"), "-o", o])
     lib = os.path.join(HERE, f"libunivid_probe{n}.so")
     subprocess.check_call([b._hipcc(), "-shared", "-fPIC", f"--offload-arch={b.ARCH}", *objs, o, "-o", lib])
     os.remove(o)

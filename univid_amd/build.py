@@ -20,10 +20,16 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-va
          "-ffp-contract=off"]
 
 
-# per-file additions (none in the product library since round 4). The diagnostic kernel tools/diag/attn_pw4.hip is built by
+# per-file additions. The diagnostic kernel tools/diag/attn_pw4.hip is built by
 # tools/diag/build_diag.py with DIAG_PW4_FLAGS: its slots are hand-placed scalar f32 operations beside MFMAs; SLP-packing them into
 # v_pk_*_f32 costs issue cycles there (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
-FILE_FLAGS = {}
+# attention.hip: -fno-honor-nans. fmaxf on values hipcc cannot prove canonical (MFMA outputs, v_permlane results, loop-carried maxima)
+# is lowered as v_max_f32 x, x, x (quieting a possible signalling NaN) in front of the real maximum: 6 of the 16 maximum instructions per
+# 32-key half of the softmax were such canonicalisations (24 of 64 VALU maxima per two key tiles; MI355X_MICROARCH.md, "inserts
+# canonicalising v_max before fmaxf on MFMA outputs"). Without NaN honouring they are gone: bit-identical outputs on NaN-free data
+# (identity on every non-NaN value; +-inf is still honoured - the masked tile's -inf scores rely on it), -1.0 ... -1.8 % on the self-
+# attention launch in a two-library same-process A/B (tools/attn_so_ab.py). A NaN in q / k still poisons its rows through exp2 and the row sum.
+FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 DIAG_PW4_FLAGS = ["-fno-slp-vectorize", "-Wno-inline-asm"]
 
 
