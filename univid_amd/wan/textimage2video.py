@@ -99,9 +99,16 @@ class _GraphedPair:
 
     What changes from step to step is data, not structure: the latent (copied into a static buffer) and the timestep (written
     into the static table of distinct timesteps - one row for t2v, {0, t} for i2v whose first-frame tokens sit at timestep 0,
-    textimage2video.py:573 - which `WanModel.forward(..., t_rows=)` takes instead of the per-token tensor). The context work
-    (text_embedding, cross-attention K / V^T) is served from WanModel's context cache, filled by the eager warm-up forward
-    before the capture. Every kernel is the one the eager path launches, in the same order: outputs are bit-identical.
+    textimage2video.py:573 - which `WanModel.forward(..., t_rows=)` takes instead of the per-token tensor). Every kernel is the
+    one the eager path launches, in the same order: outputs are bit-identical.
+
+    What changes from GENERATION to generation is the prompt. The step-constant context work (text_embedding, every block's
+    cross-attention K / V^T of it) lives in buffers the RUNNER owns - copies of what the eager warm-up forward left in WanModel's
+    context cache, installed in that cache for the duration of the capture only - and `refresh()` recomputes them IN PLACE for new
+    prompt embeddings (two small GEMMs + a norm + two copies per block: ~3 ms at TI2V-5B size). So one capture per (latent shape,
+    mode, prepared weights) serves every prompt: a new prompt costs no recapture (0.4 s at 49 frames, 1 s at 121: measured,
+    tools/diag/graph_capture_cost.py), and a prompt buffer refilled in place under torch.inference_mode() - invisible to any
+    identity / version key - cannot go stale, because WanTI2V.denoise refreshes at the start of every call (round-3 advisor finding).
     """
     def __init__(self, model, latent, context, context_null, seq_len, i2v_mask, key=None):
         dev = latent.device
@@ -115,7 +122,7 @@ class _GraphedPair:
         # here is allowed; the static buffers below are normal tensors, which inference-mode code may write in place.
         # Capture and replay run with the latent's device current: torch's capture stream belongs to the current device, and the
         # kernels follow the device of their tensors (a model on cuda:1 in a process whose current device is cuda:0).
-        with torch.inference_mode(False), torch.no_grad(), torch.cuda.device(dev):
+        with torch.inference_mode(False), torch.no_grad(), torch.cuda.device(dev), model.context_cached():
             self.lat = torch.empty(latent.shape, dtype=latent.dtype, device=dev)
             n_t = 1 if i2v_mask is None else 2
             self.tvals = torch.zeros(n_t, dtype=torch.float32, device=dev)
@@ -129,13 +136,45 @@ class _GraphedPair:
             # eager warm-up on the capture inputs: weight preparation, context cache, scratch buffers, function attributes
             model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid, True))
             torch.cuda.synchronize(dev)
-            # the graph reads the cached context tensors by address: keep them alive for as long as the graph lives, and remember
-            # which context generation they belong to (a later generation means the model has dropped them from its cache)
-            self.gen = model._ctx_gen
-            self.keep = (model._ctx_cache, [dict(b.cross_attn._kv_cache) for b in model.blocks], ctx)
+            # runner-owned copies of the context's cross-attention K / V^T, visible to the model's cache lookups during the capture only
+            kvk = (model._ctx_gen, (0, 1))
+            self.kv, theirs = [], []
+            for b in model.blocks:
+                kl, vt = b.cross_attn._kv_cache[kvk]
+                self.kv.append((kl.clone(), vt.clone()))
+                theirs.append((kl, vt))
+                b.cross_attn._kv_cache[kvk] = self.kv[-1]
+            self.keep = (model._ctx_cache, ctx)       # (the embedded contexts the captured `cat` reads; its result is unused on a cache hit)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid, True))
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.out = model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid, True))
+            finally:
+                for b, own in zip(model.blocks, theirs):
+                    if kvk in b.cross_attn._kv_cache:
+                        b.cross_attn._kv_cache[kvk] = own
+        self.ctx_ids = self._ids(context, context_null)
+
+    @staticmethod
+    def _ids(context, context_null):
+        from .model import tensor_version
+        return tuple((u.data_ptr(), tensor_version(u), tuple(u.shape)) for u in (context[0], context_null[0]))
+
+    def refresh(self, context, context_null, force=False):
+        """The runner's context buffers recomputed in place for these prompt embeddings. Skipped only when the SAME version-counted
+        tensors come back unchanged; tensors without a version counter (torch.inference_mode) are always recomputed."""
+        ids = self._ids(context, context_null)
+        if not force and ids == self.ctx_ids and all(v != -1 for _, v, _ in ids):
+            return
+        m = self.model
+        with torch.inference_mode(False), torch.no_grad(), torch.cuda.device(self.dev):
+            emb = m.embed_context([context[0], context_null[0]])          # [2, text_len, C] bf16
+            cat = torch.cat([emb[0], emb[1]], 0)
+            for blk, (kl_own, vt_own) in zip(m.blocks, self.kv):
+                kl, vt = blk.cross_attn._context_kv(cat, m.text_len, 2, None)      # kv_key None: recomputed (V^T in the shared scratch)
+                kl_own.copy_(kl)
+                vt_own.copy_(vt)
+        self.ctx_ids = ids
 
     def __call__(self, latent, t):
         with torch.cuda.device(self.dev):
@@ -278,19 +317,15 @@ class WanTI2V:
         if graph:
             # one captured graph per (latent shape, mode, contexts, prepared weights): generations that repeat them replay it
             _ensure_prepared(self.model)
-            vers = tuple((u.data_ptr(), tensor_version(u)) for u in list(context) + list(context_null))
-            # A tensor created under torch.inference_mode() has no version counter (tensor_version == -1): an in-place refill of a
-            # preallocated prompt-embeds buffer between two generations is then invisible to the key, and a reused runner would replay
-            # the cross-attention K / V^T of the OLD prompt (round-3 advisor finding). Such contexts never reuse a runner across
-            # denoise calls: the key carries a per-call token, so the graph is recaptured (inside one call the loop owns its tensors).
-            self._denoise_calls = getattr(self, "_denoise_calls", 0) + 1
-            once = self._denoise_calls if any(v == -1 for _, v in vers) else 0
-            key = (tuple(latent.shape), i2v, vers, self.model._prep_gen, once)
-            runner = self._runner if (self._runner is not None and self._runner.key == key and
-                                      self._runner.gen == self.model._ctx_gen) else None
+            # one captured graph per (latent shape, mode, prepared weights); the prompt travels through the runner's own context buffers,
+            # recomputed in place at the start of every call (_GraphedPair.refresh): no recapture for a new prompt, nothing to go stale
+            key = (tuple(latent.shape), i2v, self.model._prep_gen, self.model.text_len)
+            runner = self._runner if (self._runner is not None and self._runner.key == key) else None
             if runner is None:
                 self._runner = None      # frees the old graph's pool before the new capture
                 runner = self._runner = _GraphedPair(self.model, latent, context, context_null, seq_len, base_mask if i2v else None, key)
+            else:
+                runner.refresh(context, context_null)
         for t in timesteps:
             if runner is not None:
                 cond, uncond = runner(latent, float(t))
