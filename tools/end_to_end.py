@@ -33,7 +33,12 @@ for F in frames:
         vae = Wan2_2_VAE(device=dev, seed=0, precision=prec)
         pipe = WanTI2V(model=m, vae=vae, device=dev)
         with torch.no_grad():
-            pipe.t2v("", size=(1280, 704), frame_num=F, sampling_steps=2, seed=7, prompt_embeds=pe, negative_prompt_embeds=ne)   # warm-up
+            # warm-up of both loops (2 steps each): one-time costs - the VAE's weight preparation, the HIP-graph captures of the t2v and i2v
+            # forward pairs (one per latent shape and mode; a NEW PROMPT does not recapture) - stay out of the timed generations
+            w = pipe.t2v("", size=(1280, 704), frame_num=F, sampling_steps=2, seed=7, prompt_embeds=pe, negative_prompt_embeds=ne)
+            pipe.i2v("", w[:, 0].clamp(-1, 1).contiguous(), max_area=704 * 1280, frame_num=F, sampling_steps=2, seed=3, prompt_embeds=pe,
+                     negative_prompt_embeds=ne)
+            del w
             lat, t_den = clock(lambda: pipe.t2v("", size=(1280, 704), frame_num=F, sampling_steps=steps, seed=7, prompt_embeds=pe,
                                                 negative_prompt_embeds=ne, decode=False))
             vid, t_dec = clock(lambda: vae.decode([lat])[0])
