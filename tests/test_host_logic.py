@@ -521,3 +521,34 @@ def test_f16x3_weight_scale_rule():
         assert math.frexp(sc)[0] == 0.5 and 2.0 ** 13 <= mx * sc < 2.0 ** 14, (mx, sc)
     assert f16_weight_scale(0.0) == 1.0 and f16_weight_scale(float("inf")) == 1.0 and f16_weight_scale(float("nan")) == 1.0
 
+
+def test_ctypes_signatures_match_the_header_argument_by_argument():
+    """Every entry point's ctypes argument list (univid_amd/_lib.py: SIGNATURES) against its C declaration in include/univid_hip.h: same
+    argument COUNT and the same class per argument (pointer / long / int / float) - a drifted signature would pass garbage through the
+    C ABI without any loader error."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "univid_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+
+    def cls_c(arg):
+        arg = arg.strip()
+        if "*" in arg:
+            return "p"
+        t = arg.split()[:-1] if len(arg.split()) > 1 else arg.split()
+        t = " ".join(x for x in t if x != "const")
+        return {"long": "l", "int": "i", "float": "f", "int32_t": "i"}.get(t, "?" + t)
+
+    def cls_py(t):
+        if t in (_lib._P, ctypes.c_char_p) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            return "p"
+        return {_lib._L: "l", _lib._I: "i", _lib._F: "f"}.get(t, "?" + repr(t))
+
+    n = 0
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(uv_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr):
+        name, args = m.group(1), m.group(2).strip()
+        c = [] if args in ("", "void") else [cls_c(a) for a in args.split(",")]
+        py = [cls_py(t) for t in _lib.SIGNATURES[name]]
+        assert c == py, f"{name}: header {c} vs ctypes {py}"
+        n += 1
+    assert n == len(_lib.SIGNATURES)
+
