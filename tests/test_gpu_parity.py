@@ -2084,6 +2084,19 @@ def _split_f16_acts(x_cl):
     return both.reshape(*x_cl.shape[:-1], 2 * C).contiguous().view(torch.float32)                                 # [.., C] f32-sized
 
 
+def _phase_weights(w, a, b):
+    """[Cout, Cin, 1, 3, 3] -> the [Cout, Cin, 1, 2, 2] weights of output phase (a, b) of "nearest-exact 2x + 3x3 convolution": per output-row
+    parity the three taps of a row collapse onto two source rows ({0} | {1, 2} and {0, 1} | {2}; columns alike), summed in fp64."""
+    rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+    wp = torch.zeros(w.shape[0], w.shape[1], 1, 2, 2, dtype=torch.float64)
+    for i, dys in enumerate(rows[a]):
+        for j, dxs in enumerate(rows[b]):
+            for dy in dys:
+                for dx in dxs:
+                    wp[:, :, 0, i, j] += w[:, :, 0, dy, dx].double()
+    return wp.float()
+
+
 @pytest.mark.parametrize("entry", ["uv_conv3d_f32", "uv_conv3d_bf16x6", "uv_conv3d_f16x3"])
 def test_conv3d_kernel_geometries(entry):
     """Every convolution geometry the VAE uses, against F.conv3d / F.conv2d: the exact-f32 MFMA kernel, the same kernel with
@@ -2126,25 +2139,21 @@ def test_conv3d_kernel_geometries(entry):
     got = run(cl(x), w2, b2, 5, 12, 14, ph=1, pw=1, up=1)
     assert_f32_close(got.permute(3, 0, 1, 2), ref[0], rtol=1e-4, atol=1e-4, name="up")
     # the same layer as four 2x2 OUTPUT-PHASE launches (up = 2 + 2a + b) with the collapsed taps' weights summed beforehand
-    if entry != "uv_conv3d_f16x3":      # (the engine keeps these convolutions - raw, un-normed inputs - off the fp16 pieces)
-        rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
-        T_, H_, W_ = 5, 6, 7
-        x_cl = cl(x)
-        outp = torch.full((T_, 2 * H_, 2 * W_, 64), 7.0, device=DEV)
-        for a in (0, 1):
-            for b_ in (0, 1):
-                wp = torch.zeros(64, 64, 1, 2, 2, dtype=torch.float64)
-                for i, dys in enumerate(rows[a]):
-                    for j, dxs in enumerate(rows[b_]):
-                        for dy in dys:
-                            for dx in dxs:
-                                wp[:, :, 0, i, j] += w2[:, :, 0, dy, dx].double()
-                wq = wp.float().permute(0, 2, 3, 4, 1).reshape(64, -1).contiguous().to(DEV)
-                if entry == "uv_conv3d_bf16x6":
-                    wq = _split6(wq)
-                _lib.call(entry, _lib.ptr(x_cl), 64, T_, H_, W_, _lib.ptr(wq), _lib.ptr(b2.to(DEV)), _lib.ptr(outp), 64, T_, H_, W_, 64, 64,
-                          1, 2, 2, 1, 1, 1, 0, 1 - a, 1 - b_, 2 + 2 * a + b_, 0, None, 0, _lib.stream_ptr())
-        assert_f32_close(outp.cpu().permute(3, 0, 1, 2), ref[0], rtol=1e-4, atol=1e-4, name="up as four output phases")
+    T_, H_, W_ = 5, 6, 7
+    x_cl = cl(x)
+    outp = torch.full((T_, 2 * H_, 2 * W_, 64), 7.0, device=DEV)
+    for a in (0, 1):
+        for b_ in (0, 1):
+            wq = _phase_weights(w2, a, b_).permute(0, 2, 3, 4, 1).reshape(64, -1).contiguous().to(DEV)
+            src, extra = x_cl, ()
+            if entry == "uv_conv3d_bf16x6":
+                wq = _split6(wq)
+            elif entry == "uv_conv3d_f16x3":
+                (wq, scale), src = _split_f16_weights(wq), _split_f16_acts(x_cl)
+                extra = (scale, None)
+            _lib.call(entry, _lib.ptr(src), 64, T_, H_, W_, _lib.ptr(wq), _lib.ptr(b2.to(DEV)), _lib.ptr(outp), 64, T_, H_, W_, 64, 64,
+                      1, 2, 2, 1, 1, 1, 0, 1 - a, 1 - b_, 2 + 2 * a + b_, 0, None, 0, *extra, _lib.stream_ptr())
+    assert_f32_close(outp.cpu().permute(3, 0, 1, 2), ref[0], rtol=1e-4, atol=1e-4, name="up as four output phases")
     w3, b3 = torch.randn(128, 64, 3, 1, 1, generator=g) * 0.05, torch.randn(128, generator=g)
     y = F.conv3d(F.pad(x, (0, 0, 0, 0, 2, 0)), w3, b3)                                     # time_conv + interleave
     ref = torch.stack((y[:, :64], y[:, 64:]), 3).reshape(1, 64, 10, 6, 7)

@@ -36,8 +36,8 @@ SHAPES = [
     ("ranker q/k/v/o (64 x 256 tokens)", 16384, 768, 768, EPI_BF16),
     ("ranker fc1", 16384, 3072, 768, EPI_GELU_BF16),
     ("ranker fc2", 16384, 768, 3072, EPI_BF16),
-    ("q+k as ONE N=6144 launch", L2, 6144, 3072, EPI_BF16),       # priced at one launch gap; compare with 2 x shape 0
-    ("q+k+v-sized N=9216 launch", L2, 9216, 3072, EPI_BF16),      # (the V third would need the transposed epilogue: time bound only)
+    ("q+k as ONE N=6144 launch", L2, 6144, 3072, EPI_BF16),       # measured 652-654 us against 2 x 327.7 us (shape 0): no gain
+    ("q+k+v-sized N=9216 launch", L2, 9216, 3072, EPI_BF16),      # 960 us against 3 x 327.7 (-2.4 %; the V third would need the transposed epilogue)
 ]
 
 
