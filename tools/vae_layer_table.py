@@ -1,6 +1,6 @@
 """Per-layer table of a full-size VAE decode / encode (developer tool): every convolution launch of the engine timed with HIP events (one
 synchronisation per launch: the sum is a little above the untimed decode), grouped by geometry, with the algorithmic and - f16x3 / bf16x6 -
-the EXECUTED MFMA rate (3 / 6 passes).   python3 tools/vae_layer_table.py [decode|encode] [precision]"""
+the EXECUTED MFMA rate (3 / 6 passes).   python3 tools/vae_layer_table.py [decode|encode] [precision] [UV_OPT_CONV_HALO value: -1 auto, 0 gather kernels only, 1]"""
 import os, sys, collections, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from univid_amd import _lib
@@ -9,6 +9,8 @@ from univid_amd.wan.vae2_2 import Wan2_2_VAE
 what = sys.argv[1] if len(sys.argv) > 1 else "decode"
 prec = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
 _lib.init()
+if len(sys.argv) > 3:
+    _lib.set_option(_lib.OPT_CONV_HALO, int(sys.argv[3]))
 vae = Wan2_2_VAE(device="cuda", seed=0, precision=prec)
 g = torch.Generator(device="cuda").manual_seed(7)
 z = torch.randn(48, 13, 45, 80, device="cuda", generator=g)
