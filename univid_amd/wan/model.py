@@ -312,9 +312,17 @@ class WanAttentionBlock(nn.Module):
         else:
             self.cross_attn._cross_fused(h, ctx, Ls, Lc, x, batch, kv_key)
         # FFN (model.py:252-255)
+        # ffn.0 on rows rounded up to whole 256-row tiles where the extra tiles ride in the last, partial round of the persistent GEMM
+        # (22 880 rows x 14 336 columns: 19.47 -> 19.69 rounds, both 20) instead of a leftover-row launch behind it: the pad rows of the
+        # input are zeros, their outputs are never read (ffn.2 runs on L rows); results unchanged (a row's arithmetic is the same in both kernels)
+        Lf = _ffn0_rows(L, self.ffn_dim, dev)
+        if Lf != L:
+            # (one scratch per stream, like the V^T scratch: concurrent forwards on different streams - and a HIP-graph capture, whose
+            # scratch then lives in the graph's own memory pool - must not share it)
+            h = _zeros_cached(("ffn_in", dev, torch.cuda.current_stream(dev).cuda_stream), (Lf, C), BF16, dev)
         _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=3 * C, scale_off=4 * C, tid=tid)
-        mid = torch.empty(L, self.ffn_dim, dtype=BF16, device=dev)
-        _lib.gemm_bf16(h, self._prep["ffn0"].w, self._prep["ffn0"].b, mid, EPI_GELU_BF16, M=L)
+        mid = torch.empty(Lf, self.ffn_dim, dtype=BF16, device=dev)
+        _lib.gemm_bf16(h, self._prep["ffn0"].w, self._prep["ffn0"].b, mid, EPI_GELU_BF16, M=Lf)
         _lib.gemm_bf16(mid, self._prep["ffn2"].w, self._prep["ffn2"].b, x, EPI_GATE_RESID_F32, M=L,
                        gate=tab[:, 5 * C:], gate_tid=tid)
 
@@ -361,6 +369,22 @@ class Head(nn.Module):
 
 
 _zero_cache = {}
+
+
+_ncu = {}
+
+
+def _ffn0_rows(L, n_cols, dev):
+    """Rows to run the first FFN projection on: L, or L rounded up to 256 when the padded row tile does not add a round of 256 x 256 tiles."""
+    Lp = _round_up(L, 256)
+    if Lp == L or n_cols % 256:
+        return L
+    ncu = _ncu.get(dev)
+    if ncu is None:
+        ncu = _ncu[dev] = max(8, torch.cuda.get_device_properties(dev).multi_processor_count & ~7)
+    tn = n_cols // 256
+    full, padded = (L // 256) * tn, (Lp // 256) * tn
+    return Lp if full >= 2 * ncu and -(-padded // ncu) == -(-full // ncu) else L
 
 
 def _zeros_cached(key, shape, dtype, device):
