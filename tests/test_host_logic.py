@@ -552,3 +552,19 @@ def test_ctypes_signatures_match_the_header_argument_by_argument():
         n += 1
     assert n == len(_lib.SIGNATURES)
 
+
+
+def test_ffn0_row_padding_never_adds_a_round_of_tiles():
+    """WanAttentionBlock runs the first FFN projection on rows rounded up to whole 256-row tiles only where the padded row tile rides in
+    the last, partial round of 256 x 256 tiles (univid_amd.wan.model._ffn0_rows): never an extra round, never for small problems."""
+    from univid_amd.wan import model as M
+    M._ncu["cpu-test"] = 256
+    assert M._ffn0_rows(22880, 14336, "cpu-test") == 23040          # the metric's CFG pair: 19.47 -> 19.69 rounds
+    assert M._ffn0_rows(54560, 14336, "cpu-test") == 54784          # UniVid's default workload
+    assert M._ffn0_rows(22784, 14336, "cpu-test") == 22784          # whole tiles already
+    assert M._ffn0_rows(22235, 14336, "cpu-test") == 22235          # 18.81 -> 19.03 rounds: the pad would cost a round
+    assert M._ffn0_rows(1000, 14336, "cpu-test") == 1000            # under two rounds of tiles: the small-tile path
+    assert M._ffn0_rows(22880, 14400, "cpu-test") == 22880          # columns not in whole tiles: not the persistent kernel's shape
+    for L in range(2048, 60000, 997):
+        Lp = M._ffn0_rows(L, 14336, "cpu-test")
+        assert Lp == L or (Lp % 256 == 0 and 0 < Lp - L < 256 and -(-(Lp // 256 * 56) // 256) == -(-(L // 256 * 56) // 256))
