@@ -2218,7 +2218,9 @@ def test_conv3d_halo_kernel_geometries(entry):
     # (Cout 12: the decoder's head convolution - the f16x3 entry has a narrow-output halo kernel for it, the others keep the gather kernel)
     for (T, H, W, ci, co, kt) in ((3, 19, 23, 64, 128, 3), (2, 8, 32, 32, 256, 3), (2, 40, 70, 64, 128, 3), (4, 16, 64, 96, 128, 1),
                                   (2, 19, 23, 64, 160, 3), (2, 16, 33, 32, 320, 3), (3, 19, 40, 64, 12, 3), (2, 8, 32, 32, 16, 1),
-                                  (2, 17, 40, 128, 128, 3), (3, 16, 64, 64, 256, 1)):
+                                  (2, 17, 40, 128, 128, 3), (3, 16, 64, 64, 256, 1),
+                                  # frames that cut into fewer 16 x 16 than 8 x 32 patches (the 45 x 80 stage: 15 against 18): the f16x3 entry's square-patch form
+                                  (2, 45, 80, 64, 128, 3), (1, 13, 48, 64, 256, 1), (2, 16, 16, 64, 128, 3)):
         x = torch.randn(1, ci, T, H, W, generator=g)
         w, b = torch.randn(co, ci, kt, 3, 3, generator=g) * 0.05, torch.randn(co, generator=g)
         res = torch.randn(T, H, W, co, generator=g).to(DEV)

@@ -26,9 +26,13 @@ typedef __attribute__((address_space(3))) void lds_void_g;
 
 // BN = output channels per workgroup: 128 with two-tap steps (four 16-KiB weight tiles), or 160 for the encoder's 160 / 320-channel stages with
 // ONE tap per step (two 20-KiB tiles: 126 KiB of LDS; two-tap steps would need 166 KiB) - the step length was measured not to matter (§9 round 4).
-template <int BN = 128, int TAPS = 2>
+// TW = patch width: 32 (8 x 32 patches) or 16 (16 x 16: for frames such as 45 x 80 that cut into fewer 16 x 16 than 8 x 32 patches - 15 against
+// 18; a pixel's sum runs over (channel block, tap) in the same order whatever the patch, so the results do not depend on it).
+template <int BN = 128, int TAPS = 2, int TW = 32>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3d_halo_f16_kernel(ConvArgs p) {
-    constexpr int TW = 32, TH = 8, HW_ = TW + 2, NHP = (TH + 2) * HW_;       // 340 halo pixels
+    constexpr int TH = 256 / TW, HW_ = TW + 2, NHP = (TH + 2) * HW_;         // 340 / 324 halo pixels
+    constexpr int FPR = TW / 16, RPW = TH / 4;                               // 16-pixel fragments per patch row; patch rows per wave row group
+    static_assert(TW == 32 || TW == 16, "patch width");
     constexpr int NW = 8, TM = 4, TN = BN / 32;
     constexpr int H_PIECES = (NHP + 7) / 8;                                  // 43 one-KiB pieces (8 pixels x 128 B)
     constexpr int HALO_BYTES = H_PIECES * 1024;                              // 44 032
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int frow = lane & 15, fq = lane >> 4;
     int hpb[TM];                     // halo pixel of this lane's output pixel of fragment j for tap (0, 0)
 #pragma unroll
-    for (int j = 0; j < TM; ++j) hpb[j] = (wm * 2 + (j >> 1)) * HW_ + (j & 1) * 16 + frow;
+    for (int j = 0; j < TM; ++j) hpb[j] = (wm * RPW + j / FPR) * HW_ + (j % FPR) * 16 + frow;
     int w_off[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float out_scale = p.act_scale ? p.out_scale * *p.act_scale : p.out_scale;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int py = wm * 2 + (j >> 1), px = (j & 1) * 16 + frow;
+        const int py = wm * RPW + j / FPR, px = (j % FPR) * 16 + frow;
         const int y = ty0 + py, x = tx0 + px;
         if (y >= p.Hout || x >= p.Wout) continue;
         const long m = ((long)tf * p.Hout + y) * p.Wout + x;
@@ -333,6 +337,12 @@ __global__ __launch_bounds__(512) void conv3d_halo_f16_n16_kernel(ConvArgs p) {
 // Which f16x3 convolutions take this kernel: the geometry rule of uv_conv3d_halo_eligible (3x3 spatial taps, stride 1, padding 1, plain or
 // behind the 2x upsampling, whole 32-channel input blocks and 128-wide output tiles) and enough tiles PER FRAME to fill the chip at four
 // frames per pass. uv_set_option(UV_OPT_CONV_HALO, 0 | 1) forces never / whenever the geometry fits, as for the other arithmetics.
+// 16 x 16 patches where a frame cuts into FEWER of them than 8 x 32 ones (45 x 80: 3 x 5 = 15 against 6 x 3 = 18; 360 x 640: 920 against 900). A
+// per-frame rule, and the results do not depend on the patch shape anyway (the kernel's note on TW).
+static bool halo16_square_patches(const ConvArgs& a) {
+    return (long)((a.Hout + 15) / 16) * ((a.Wout + 15) / 16) < (long)((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
+}
+
 bool uv_conv3d_halo16_eligible(const ConvArgs& a) {
     const int force = uv_option(UV_OPT_CONV_HALO);
     if (force == 0) return false;
@@ -347,8 +357,8 @@ bool uv_conv3d_halo16_eligible(const ConvArgs& a) {
     // 128-wide output tiles (two-tap steps pair the channel groups: even counts only), or whole 160-wide ones (the encoder's 160 / 320-channel stages)
     const int bn = a.Cout % 128 == 0 ? 128 : a.Cout % 160 == 0 ? 160 : 0;
     if (bn == 0 || (bn == 128 && ((a.kt * (a.Cin >> 5)) & 1))) return false;
-    const long tiles = (long)((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * (a.Cout / bn);
-    return force == 1 || 4 * tiles >= uv_num_cus();
+    const long patches = bn == 128 && halo16_square_patches(a) ? (long)((a.Hout + 15) / 16) * ((a.Wout + 15) / 16) : (long)((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
+    return force == 1 || 4 * patches * (a.Cout / bn) >= uv_num_cus();
 }
 
 int uv_launch_conv3d_halo16(ConvArgs& a, hipStream_t stream) {
@@ -370,6 +380,12 @@ int uv_launch_conv3d_halo16(ConvArgs& a, hipStream_t stream) {
     }
     a.tiles_n = a.Cout / 128;
     const size_t lds = 2 * 43 * 1024 + 4 * 128 * 128;                        // two halo images + four weight tiles = 150 KiB
+    if (halo16_square_patches(a)) {
+        a.tiles_m = a.Tout * ((a.Hout + 15) / 16) * ((a.Wout + 15) / 16);
+        UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)conv3d_halo_f16_kernel<128, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((conv3d_halo_f16_kernel<128, 2, 16>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+        return 0;
+    }
     UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)conv3d_halo_f16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((conv3d_halo_f16_kernel<128>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
     return 0;
