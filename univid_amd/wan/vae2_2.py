@@ -427,7 +427,13 @@ class _Engine:
         if rs.mode == "upsample3d" and not first_chunk:
             op = self.ops[rs.time_conv]
             ring, after = self.conv_input(op, H, W, T, lambda dst: dst.copy_(x))
-            x = self._conv(op, ring, CACHE_T + T, H, W, T, H, W, t_off=0, interleave=1)
+            if self.precision == "f16x3" and C % 32 == 0 and ring.is_contiguous():
+                # raw residual-stream rows: the whole [cache | pass] input as fp16 pieces under ONE device-found scale (the cache frames
+                # stay f32 in the ring, so passes with different scales never mix), three fp16 passes instead of bf16x6's six
+                r16, sc = self._split16(ring)
+                x = self._conv(op, r16, CACHE_T + T, H, W, T, H, W, t_off=0, interleave=1, in_split=2, act_scale=sc)
+            else:
+                x = self._conv(op, ring, CACHE_T + T, H, W, T, H, W, t_off=0, interleave=1)
             if after is not None:
                 after()
             T = 2 * T
