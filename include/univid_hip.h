@@ -224,7 +224,8 @@ int uv_conv3d_f16x3(const float* in, long ld_in, int Tin, int Hin, int Win, cons
 /* x [P, C] f32 rows (any feature map; C % 32 == 0) -> `out`: the same bytes per pixel holding [C/32][32 hi | 32 lo] IEEE fp16 pieces of
  * x * s, s a per-tensor power of two found on the device: 1 while max|x| < 2^15 (then this equals uv_vae_rms_silu's split_out=2 format of
  * the same values), else the scale that puts max|x| into [2^14, 2^15). scale: two device floats; scale[0] <- 1 / s for uv_conv3d_f16x3's
- * act_scale, scale[1] = work space. Three stream-ordered operations (memset, max-reduction, split); no host round trip. */
+ * act_scale, scale[1] = work space. Three stream-ordered operations (memset; split under s = 1 with the maximum found in the same pass; a second
+ * launch that writes 1 / s and re-splits only if s != 1); no host round trip. `out` must not alias `x`. */
 int uv_vae_split_f16(const float* x, long ld, float* out, long ld_out, long P, int C, float* scale, void* stream);
 /* w [n] f32 (rows of K, K % 32 == 0) -> [n/32][32 hi | 32 lo] IEEE fp16 with hi = fp16(w * scale), lo = fp16(w * scale - hi); scale = 2^s */
 int uv_split_weights_f16x3(const float* w, void* out, long n, float scale, void* stream);

@@ -308,45 +308,34 @@ extern "C" int uv_vae_video_out(const float* y, long ld, float* vid, int F, int 
 
 // ---- f16x3 operands for convolutions whose input is NOT an RMS_norm output (Resample's 3x3 convolutions: raw residual-stream rows) -----------
 // uv_conv3d_f16x3 needs |x| < 65 504. A raw feature map has no static bound, so the split is taken under a PER-TENSOR power-of-two scale found
-// on the device: pass 1 = max |x| over the tensor (wave + block reduction, one atomicMax on the f32 bits per block), pass 2 = hi / lo fp16
-// pieces of x * s with s = 1 while max |x| < 2^15 (every realistic activation: then this is exactly what uv_vae_rms_silu(split_out=2) writes)
+// on the device: hi / lo fp16 pieces of x * s with s = 1 while max |x| < 2^15 (every realistic activation: then this is exactly what
+// uv_vae_rms_silu(split_out=2) writes; the maximum is found in the same pass, see split_f16_scaled_kernel)
 // and s = 2^(14 - floor(log2 max)) above. 1 / s goes to scale[0]; the convolution multiplies its result by it (exact). No host round trip.
-__global__ __launch_bounds__(256) void absmax_f32_kernel(const float* x, long ld, long P, int C, unsigned* out_bits) {
+// SPECULATIVE = the first launch: pieces under s = 1 AND the tensor's max |x| in the same pass over x (one atomicMax on the f32 bits per block: non-negative
+// floats order like their bit patterns; fmaxf drops NaNs - a NaN input leaves the scale at that of the finite values and propagates through the
+// products). !SPECULATIVE = the second launch: writes 1 / s and, only if s != 1 (max |x| >= 2^15: no realistic activation), splits again under s;
+// otherwise every block returns after one load. (Round 4: the separate max pass in front of the split cost a second read of every raw tensor.)
+template <bool SPECULATIVE>
+__global__ __launch_bounds__(256) void split_f16_scaled_kernel(const float* x, long ld, float* out, long ld_out, long P, int C, float* scale) {
+    float s = 1.f;
+    if constexpr (!SPECULATIVE) {
+        const float mx = __builtin_bit_cast(float, *(const unsigned*)(scale + 1));
+        if (mx >= 32768.f && mx < INFINITY) {
+            int ex;
+            frexpf(mx, &ex);                                            // mx = f * 2^ex, f in [0.5, 1)
+            s = ldexpf(1.f, 15 - ex);                                   // mx * s in [2^14, 2^15)
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) scale[0] = 1.f / s;    // exact (power of two); only this thread writes it, everyone reads scale[1]
+        if (s == 1.f) return;                                           // the speculative pieces stand
+    }
     const int nv = C >> 2;
     const long total = P * nv;
     float m = 0.f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long row = i / nv;
-        const f32x4 v = *(const f32x4*)(x + row * ld + (i - row * nv) * 4);
-        m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
-        // (fmaxf drops NaNs: a NaN input leaves the scale at that of the finite values and propagates through the products)
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    __shared__ float part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-        atomicMax(out_bits, __builtin_bit_cast(unsigned, m));      // non-negative floats order like their bit patterns
-    }
-}
-
-__global__ __launch_bounds__(256) void split_f16_scaled_kernel(const float* x, long ld, float* out, long ld_out, long P, int C, float* scale) {
-    const float mx = __builtin_bit_cast(float, *(const unsigned*)(scale + 1));
-    float s = 1.f;
-    if (mx >= 32768.f && mx < INFINITY) {
-        int ex;
-        frexpf(mx, &ex);                                            // mx = f * 2^ex, f in [0.5, 1)
-        s = ldexpf(1.f, 15 - ex);                                   // mx * s in [2^14, 2^15)
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) scale[0] = 1.f / s;    // exact (power of two); only this thread writes it, everyone reads scale[1]
-    const int nv = C >> 2;
-    const long total = P * nv;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long row = i / nv;
         const int c = (int)(i - row * nv) * 4;
         const f32x4 v = *(const f32x4*)(x + row * ld + c);
+        if constexpr (SPECULATIVE) m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
         _Float16 hi[4], lo[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -359,19 +348,31 @@ __global__ __launch_bounds__(256) void split_f16_scaled_kernel(const float* x, l
         *(u32x2*)ob = (u32x2){pk(hi[0], hi[1]), pk(hi[2], hi[3])};
         *(u32x2*)(ob + 32) = (u32x2){pk(lo[0], lo[1]), pk(lo[2], lo[3])};
     }
+    if constexpr (SPECULATIVE) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        __shared__ float part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+            atomicMax((unsigned*)(scale + 1), __builtin_bit_cast(unsigned, m));
+        }
+    }
 }
 
 extern "C" int uv_vae_split_f16(const float* x, long ld, float* out, long ld_out, long P, int C, float* scale, void* stream) {
     UV_CHECK_ARG(x && out && scale && P > 0 && C > 0 && C % 32 == 0 && ld % 4 == 0 && ld_out % 4 == 0 && ld >= C && ld_out >= C,
                  "uv_vae_split_f16: bad arguments (C=%d must be a multiple of 32)", C);
+    UV_CHECK_ARG((const void*)x != (const void*)out, "uv_vae_split_f16: out must not alias x (the second launch may re-read x)");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(scale, 0, 2 * sizeof(float), st) != hipSuccess) {
         uv_set_error("uv_vae_split_f16: memset failed");
         return -2;
     }
     const unsigned blocks = (unsigned)min((P * (C >> 2) + 255) / 256, (long)8192);
-    hipLaunchKernelGGL(absmax_f32_kernel, dim3(blocks), dim3(256), 0, st, x, ld, P, C, (unsigned*)(scale + 1));
-    hipLaunchKernelGGL(split_f16_scaled_kernel, dim3(blocks), dim3(256), 0, st, x, ld, out, ld_out, P, C, scale);
+    hipLaunchKernelGGL(split_f16_scaled_kernel<true>, dim3(blocks), dim3(256), 0, st, x, ld, out, ld_out, P, C, scale);
+    hipLaunchKernelGGL(split_f16_scaled_kernel<false>, dim3(blocks), dim3(256), 0, st, x, ld, out, ld_out, P, C, scale);
     UV_CHECK_LAUNCH("uv_vae_split_f16");
     return 0;
 }
