@@ -1941,6 +1941,12 @@ def test_vae_split_f16_per_tensor_scale():
         xs, sc = torch.empty_like(x_cl), torch.full((2,), 7.0, device=DEV)
         _lib.call("uv_vae_split_f16", _lib.ptr(x_cl), 64, _lib.ptr(xs), 64, x_cl.numel() // 64, 64, _lib.ptr(sc), _lib.stream_ptr())
         inv = float(sc[0])
+        # rows with a larger leading dimension (the strided form of the kernel) must give the same pieces and the same scale
+        wide_in, wide_out, sc2 = torch.full((x_cl.numel() // 64, 96), 5.0, device=DEV), torch.zeros(x_cl.numel() // 64, 96, device=DEV), torch.zeros(2, device=DEV)
+        wide_in[:, :64] = x_cl.view(-1, 64)
+        _lib.call("uv_vae_split_f16", _lib.ptr(wide_in), 96, _lib.ptr(wide_out), 96, x_cl.numel() // 64, 64, _lib.ptr(sc2), _lib.stream_ptr())
+        assert torch.equal(wide_out[:, :64].contiguous().view(torch.int32), xs.view(-1, 64).view(torch.int32)) and torch.equal(sc2, sc)
+        assert float(wide_out[:, 64:].abs().max()) == 0.0
         if not big:
             assert inv == 1.0 and torch.equal(xs.view(torch.int32), _split_f16_acts(x_cl).view(torch.int32))
         else:
