@@ -193,6 +193,72 @@ def default_shape_probe(model, device, cfg, steps=3):
             "finite": bool(torch.isfinite(lat).all().item())}
 
 
+def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=10):
+    """UniVid's OWN entry point on the metric's shape: CrossAttentionFusionPipeline.generate_video_with_bagel_context (reference
+    models/model_pipeline.py:2577-2655, what inference.py:311,377 calls) -> Wan22ContextWrapper.generate -> WanTI2V.t2v, with inference.py's
+    settings (:52-80: 50 steps, dynamic text weight cosine 1.3 -> 1.0 over int(50 * 0.4) = 20 forwards = the first 10 steps), a stub BAGEL
+    extractor returning [1, 128, 3584] tokens, the HIP ContextProjector, prompt embeddings passed in, decode=False. Timed: ONE whole
+    50-step generation (after a 2-step one that captures the graph), wall clock around the call. Beside it the same entry point with
+    native_text_weight=False: the reference's closures on every WanCrossAttention.forward and the DiT forward, executed on the model's
+    generic path (two batch-1 forwards per step, context K / V re-projected in every block, un-fused residual, no graph).
+    OUTSIDE the metric's timed region; the metric's own loop is WanTI2V.denoise's plain step, which this path equals once w = 1."""
+    import types
+    from univid_amd import _lib
+    from univid_amd.model_pipeline import ContextProjector, CrossAttentionConfig, CrossAttentionFusionPipeline
+    from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
+    g = torch.Generator(device=device).manual_seed(21)
+    tokens = torch.randn(1, 128, 3584, device=device, generator=g).to(torch.bfloat16)
+    bagel = types.SimpleNamespace(extract_semantic_tokens=lambda text, image: tokens)
+    ccfg = CrossAttentionConfig(use_lora=False, use_dynamic_text_weight=True, text_weight_max=1.3, text_weight_min=1.0, text_weight_schedule="cosine",
+                                text_weight_transition_ratio=0.4, total_sampling_steps=SAMPLING_STEPS)
+    with torch.device(device):
+        proj = ContextProjector(ccfg)
+    from univid_amd import detinit
+    detinit.init_module_(proj, 5)
+    proj = proj.eval()
+    pipe = WanTI2V(TI2VConfig, model=model, device=device)
+    noise = torch.randn(*LATENT, device=device, generator=g)
+    emb = [torch.randn(77, cfg["text_dim"], device=device, generator=g) * 0.1]
+    emb_n = [torch.randn(12, cfg["text_dim"], device=device, generator=g) * 0.1]
+    kw = dict(guidance_scale=GUIDE, frames=49, size=(1280, 704), shift=SHIFT, decode=False, prompt_embeds=emb, negative_prompt_embeds=emb_n, noise=noise)
+    res = {"entry": "CrossAttentionFusionPipeline.generate_video_with_bagel_context(prompt_embeds=, decode=False) -> Wan22ContextWrapper -> WanTI2V.t2v",
+           "workload": f"the metric's latent {list(LATENT)}, L={L_TOKENS}; inference.py's schedule: cosine text weight 1.3 -> 1.0 over the first "
+                       f"{int(SAMPLING_STEPS * 0.4)} forwards of {SAMPLING_STEPS} steps, first 128 context rows, all {cfg['num_layers']} blocks"}
+
+    def timed(fusion, n):
+        torch.cuda.synchronize()
+        c0, cpu0, t0 = _lib.CALL_COUNT, time.process_time(), time.perf_counter()
+        lat, _ = fusion.generate_video_with_bagel_context("a prompt", steps=n, **kw)
+        cpu1 = time.process_time()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return lat, {"steps": n, "seconds": round(dt, 3), "ms_per_step": round(dt / n * 1e3, 2), "steps_per_sec": round(n / dt, 4),
+                     "host_cpu_ms_per_step": round((cpu1 - cpu0) / n * 1e3, 3), "launches_per_step": round((_lib.CALL_COUNT - c0) / n, 1),
+                     "finite": bool(torch.isfinite(lat).all().item())}
+
+    with torch.no_grad():
+        fusion = CrossAttentionFusionPipeline(ccfg, wan_pipeline=pipe, bagel_extractor=bagel, context_projector=proj)
+        fusion.generate_video_with_bagel_context("a prompt", steps=2, **kw)            # capture + kernel load
+        lat_n, res["native"] = timed(fusion, steps)
+        res["native"]["graph"] = pipe._runner is not None
+        res["native"]["note"] = ("whole generation incl. ContextProjector, graph-buffer refreshes of the weighted steps, sampler set-up; "
+                                 "text weight as data on the fast path (WanModel.set_text_weight / _GraphedPair.apply)")
+        # same first steps through both mechanisms: bit-identical latents (also tests/test_pipeline_path.py)
+        lat_a, _ = fusion.generate_video_with_bagel_context("a prompt", steps=closure_steps, **kw)
+        lat_a = lat_a.clone()
+        fusion.cleanup_resources()
+        pipe._runner = None
+        torch.cuda.empty_cache()
+        closures = CrossAttentionFusionPipeline(ccfg, wan_pipeline=pipe, bagel_extractor=bagel, context_projector=proj, native_text_weight=False)
+        closures.generate_video_with_bagel_context("a prompt", steps=1, **kw)
+        lat_c, res["closures"] = timed(closures, closure_steps)
+        res["closures"]["note"] = "the reference's mechanism literally (forward closures), on the model's generic path; what rounds 1-4 ran under this entry point"
+        closures.cleanup_resources()
+        res["native_equals_closures_bitwise"] = bool(torch.equal(lat_a, lat_c))
+    res["ms_per_step"], res["host_cpu_ms_per_step"], res["launches_per_step"] = (res["native"][k] for k in ("ms_per_step", "host_cpu_ms_per_step", "launches_per_step"))
+    return res
+
+
 def stress_shape_probe(device, base_cfg, blocks=2):
     """north_star's utilisation target is quoted at the literal 49 x 90 x 160 latent (L = 176 400 tokens), where a whole 30-block step
     takes 22 s (profiles/r02_bench_shapeB_L176400.json: 47.3 %). This times the SAME forward (cond + uncond stacked, full TI2V-5B width)
@@ -395,6 +461,7 @@ def main():
                     "WanTI2V.denoise does for the plain single-process loop): same kernels, same order, bit-identical; the host then issues a handful "
                     "of launches per step instead of ~500. auto = as WanTI2V.denoise decides")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
+    ap.add_argument("--no-pipeline-path", action="store_true", help="skip the (untimed-region) generation through CrossAttentionFusionPipeline, UniVid's own entry point")
     ap.add_argument("--no-default-shape", action="store_true", help="skip the (untimed-region) 3-step run at UniVid's default 121-frame latent (L = 27 280)")
     ap.add_argument("--no-stress-shape", action="store_true", help="skip the (untimed-region) 2-block probe at the literal 49x90x160 latent")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer DiT blocks (result is NOT the metric)")
@@ -591,6 +658,14 @@ def main():
         if args.kernel_times:
             out["kernel_times"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in ktimes.items()}
         out["rccl_ranks"] = world if world > 1 else 0
+        if world == 1 and not args.no_pipeline_path and args.shape == "A":
+            runner = None
+            torch.cuda.empty_cache()
+            try:
+                out["pipeline_path"] = pipeline_path_probe(model, device, cfg)
+                out["pipeline_path"]["vs_headline_ms_per_step"] = round(out["pipeline_path"]["ms_per_step"] / out["ms_per_step"], 4)
+            except Exception as ex:      # a side measurement: never fails the bench
+                out["pipeline_path"] = {"error": repr(ex)[:300]}
         if world == 1 and not args.no_default_shape and not args.layers and args.shape == "A":
             try:
                 out["default_shape"] = default_shape_probe(model, device, cfg)

@@ -142,6 +142,11 @@ int uv_add_rows_f32(const float* mod, const float* e0, float* out, int R, long n
 int uv_cast_f32_bf16(const float* in, void* out, long n, void* stream);
 /* x_f32 += float(y_bf16): un-fused residual used when WanCrossAttention.forward has been re-assigned (UniVid's hook). */
 int uv_add_bf16_resid(float* x, long ldx, const void* y, long ldy, int L, int C, void* stream);
+/* UniVid's dynamic text weight on the embedded context of ONE sample (Wan22ContextWrapper's per-layer hook,
+ * models/model_pipeline.py:1779-1797: `context * weight_mask`, weight_mask = ones_like(context) with rows [0, text_len) `*= w`):
+ * out[r] = bf16(in[r] * bf16(w)) for r < n_scaled, out[r] = in[r] for n_scaled <= r < R. in / out bf16 [R, C], C % 8 == 0; in == out allowed.
+ * The result is what the K / V projections of the hooked layers read (WanModel.set_text_weight). */
+int uv_text_weight_rows_bf16(const void* in, long ldi, void* out, long ldo, int R, int n_scaled, int C, float w, void* stream);
 
 /* out[r] = x[r] / max(||x[r]||_2, eps): torch.nn.functional.normalize(dim=-1) of the SigLIP2 ranker's embeddings
  * (models/BAGEL/eval_understanding.py:185,195). */

@@ -1105,7 +1105,7 @@ def test_graph_runner_serves_new_prompts_without_recapture_and_never_goes_stale(
         ctx2, ctxn2 = [g["ctx"].to(DEV).clone()], [g["ctx_null"].to(DEV).clone()]
         d1 = pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, graph=True).clone()
         assert pipe._runner is r1 and torch.equal(d1, a_graph)
-        d2 = pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, graph=True)       # unchanged tensors: the refresh is skipped
+        d2 = pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, graph=True)       # unchanged tensors (round 5: refreshed all the same - no identity shortcut)
         assert torch.equal(d1, d2)
         ctx2[0].mul_(-0.5)                                 # in-place edit bumps the version: refreshed
         d3 = pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, graph=True)

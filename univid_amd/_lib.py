@@ -50,6 +50,7 @@ SIGNATURES = {
     "uv_add_rows_f32": [_P, _P, _P, _I, _L, _P],
     "uv_cast_f32_bf16": [_P, _P, _L, _P],
     "uv_add_bf16_resid": [_P, _L, _P, _L, _I, _I, _P],
+    "uv_text_weight_rows_bf16": [_P, _L, _P, _L, _I, _I, _I, _F, _P],
     "uv_cfg_convert": [_P, _P, _P, _F, _F, _P, _P, _L, _P],
     "uv_unipc_corrector": [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _L, _P],
     "uv_unipc_predictor": [_P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _P],
@@ -298,6 +299,16 @@ def rmsnorm_rope(x, out, weight, L, C, D, eps, freqs=None, grid=(0, 0, 0), row0=
     _chk(out, torch.bfloat16, "rmsnorm_rope.out")
     call("uv_rmsnorm_rope", ptr(x), x.stride(0), ptr(out), out.stride(0), ptr(weight), L, C, D, float(eps), ptr(freqs),
          int(grid[0]), int(grid[1]), int(grid[2]), int(row0), stream_ptr())
+    return out
+
+
+def text_weight_rows(x, out, n_scaled, w):
+    """out[r] = bf16(x[r] * bf16(w)) for the first n_scaled rows of one sample's embedded context [R, C] bf16, the other rows copied:
+    UniVid's dynamic text weight (model_pipeline.py:1787-1797)."""
+    _chk(x, torch.bfloat16, "text_weight_rows.x")
+    _chk(out, torch.bfloat16, "text_weight_rows.out")
+    R, C = x.shape
+    call("uv_text_weight_rows_bf16", ptr(x), x.stride(0), ptr(out), out.stride(0), R, int(n_scaled), C, float(w), stream_ptr())
     return out
 
 

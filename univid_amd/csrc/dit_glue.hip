@@ -581,6 +581,45 @@ extern "C" int uv_add_bf16_resid(float* x, long ldx, const void* y, long ldy, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// UniVid's dynamic text weight (models/model_pipeline.py:1787-1797): `context * weight_mask` on the bf16 embedded context, where
+// weight_mask = ones_like(context) with its first text_len rows multiplied IN PLACE by the python float w - i.e. the mask holds
+// bf16(w), and every scaled element is bf16(float(c) * float(bf16(w))) (the product of two bf16 values is exact in f32: one rounding).
+// Rows >= n_scaled are copied (x * bf16(1) = x). One launch per sample; the result feeds the K / V projections.
+// ------------------------------------------------------------------------------------------------
+__global__ void text_weight_rows_kernel(const bf16_t* in, long ldi, bf16_t* out, long ldo, int R, int n_scaled, int C, float wb) {
+    const int c8 = C >> 3;
+    const long total = (long)R * c8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c8;
+        const int c = (int)(i % c8) * 8;
+        u32x4 v = *(const u32x4*)(in + r * ldi + c);
+        if (r < n_scaled) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] = pack_bf2(__fmul_rn(bf2f((bf16_t)(v[j] & 0xffff)), wb), __fmul_rn(bf2f((bf16_t)(v[j] >> 16)), wb));
+        }
+        *(u32x4*)(out + r * ldo + c) = v;
+    }
+}
+
+extern "C" int uv_text_weight_rows_bf16(const void* in, long ldi, void* out, long ldo, int R, int n_scaled, int C, float w, void* stream) {
+    UV_CHECK_ARG(in && out && R > 0 && n_scaled >= 0 && n_scaled <= R && C > 0 && C % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0,
+                 "uv_text_weight_rows_bf16: bad arguments (C and the leading dimensions must be multiples of 8)");
+    UV_CHECK_ARG((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "uv_text_weight_rows_bf16: misaligned pointers");
+    // the mask element torch builds: ones(bf16) *= w  ->  bf16(1.0f * (float)w)
+    const uint32_t wbits = __builtin_bit_cast(uint32_t, w);
+    uint32_t rb = wbits + 0x7fffu + ((wbits >> 16) & 1u);          // round-to-nearest-even to the top 16 bits (w is finite: checked)
+    UV_CHECK_ARG((wbits & 0x7f800000u) != 0x7f800000u, "uv_text_weight_rows_bf16: w must be finite");
+    rb &= 0xffff0000u;
+    const float wb = __builtin_bit_cast(float, rb);
+    const int blocks = (int)min(((long)R * (C / 8) + 255) / 256, (long)2048);
+    hipLaunchKernelGGL(text_weight_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ldi, (bf16_t*)out, ldo,
+                       R, n_scaled, C, wb);
+    UV_CHECK_LAUNCH("uv_text_weight_rows_bf16");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row-wise L2 normalisation: out[r] = x[r] / max(||x[r]||_2, eps)  (torch.nn.functional.normalize(dim=-1), the cosine
 // scoring of the SigLIP2 ranker: models/BAGEL/eval_understanding.py:185,195). One wave per row.
 // ------------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@ Behaviour kept on purpose: the text-encoder override of the refe
 and rescales the first min(bagel_sequence_length, text_len // 2) rows of the embedded context by w(step), where
 `step` counts DiT FORWARD calls (2 per sampler step).
 """
+import contextlib
 import logging
 import math
 import os
@@ -78,14 +79,52 @@ class CrossAttentionConfig:
             self.bagel_cross_attn_layers = [8, 15, 22, 28]
 
 
-class Wan22ContextWrapper:
-    """model_pipeline.py:1624-1900. Wraps a WanTI2V; hooks every `WanCrossAttention.forward` of its DiT."""
+class _TextWeightSchedule:
+    """The state of one generation under UniVid's dynamic text weight, as WanTI2V.denoise reads it: the wrapper's forward counter
+    (model_pipeline.py:1844-1886: reset per generate(), +1 per DiT forward, the weight of a forward = _calculate_text_weight(counter)),
+    the hook's conditions (:1767-1773: BAGEL context set, dynamic weight on) evaluated when the forward runs, the number of scaled
+    rows (:1790 min(bagel_sequence_length, context rows // 2)) and the hooked layers (`injection_layers`, None = all)."""
 
-    def __init__(self, original_wan_pipeline, context_projector, logger, config: CrossAttentionConfig):
+    def __init__(self, wrapper):
+        self.wrapper = wrapper
+
+    @property
+    def layers(self):
+        return self.wrapper.injection_layers
+
+    def rows(self, context_rows):
+        return min(self.wrapper.config.bagel_sequence_length, context_rows // 2)
+
+    def next_weight(self):
+        wr = self.wrapper
+        wr.set_timestep(wr.sampling_step_counter)
+        wr.sampling_step_counter += 1
+        on = wr.use_bagel_context and wr.bagel_context is not None and wr.config.use_dynamic_text_weight
+        return float(wr.text_weight_multiplier) if on else 1.0
+
+    def next_pair(self):
+        """Weights of the cond and the uncond forward of the next sampler step (the reference runs them in this order)."""
+        wc = self.next_weight()
+        return wc, self.next_weight()
+
+
+class Wan22ContextWrapper:
+    """model_pipeline.py:1624-1900. Wraps a WanTI2V and applies UniVid's dynamic text weight to every WanCrossAttention of its DiT.
+
+    native=True (default): the schedule is handed to the loop as DATA - WanTI2V.denoise asks for the two weights of each step's CFG pair
+    and the DiT scales the context rows in front of the hooked blocks' K / V projections (WanModel.set_text_weight; under the HIP graph
+    the runner's K / V^T buffers are refreshed in place) - so the generation runs on the fast path (stacked CFG pair, cached context
+    work, fused residual epilogue, graph replay) and is bit-identical to the closures' result. Nothing is re-assigned on the model.
+    native=False: the reference's mechanism literally - a closure re-assigned as `forward` on every WanCrossAttention instance plus a
+    counting closure as the DiT's `forward` during generate() (:1742-1810, 1856-1868) - which the model honours on its generic path.
+    """
+
+    def __init__(self, original_wan_pipeline, context_projector, logger, config: CrossAttentionConfig, native: bool = True):
         self.original_pipeline = original_wan_pipeline
         self.context_projector = context_projector
         self.logger = logger
         self.config = config
+        self.native = bool(native)
         self.dit_model = original_wan_pipeline.model
         self.original_forward_methods = {}
         self.fusion_alpha = 1.0
@@ -118,34 +157,35 @@ class Wan22ContextWrapper:
         self.text_weight_multiplier = self._calculate_text_weight(timestep)
 
     def _hook_cross_attention_layers(self):
-        """:1742-1810: re-assign `forward` on every WanCrossAttention instance."""
+        """:1742-1810: finds every WanCrossAttention (by class name, in module order = layer index). native: records them - the
+        scaling itself happens inside the DiT; otherwise re-assigns `forward` on every instance, as the reference does."""
         layer_idx = 0
         for name, module in self.dit_model.named_modules():
             if module.__class__.__name__ != "WanCrossAttention":
                 continue
             original_forward = module.forward
             self.original_forward_methods[name] = original_forward
-
-            def make(layer_index, original_fn):
-                def hooked_forward(x, context, context_lens, *args, **kwargs):
-                    if (self.use_bagel_context and self.bagel_context is not None
-                            and (self.injection_layers is None or layer_index in self.injection_layers)
-                            and self.config.use_dynamic_text_weight and self.text_weight_multiplier != 1.0
-                            and context is not None):
-                        seq_len = context.shape[1] if context.dim() > 1 else context.shape[0]
-                        text_len = min(self.config.bagel_sequence_length, seq_len // 2)
-                        weight_mask = torch.ones_like(context)
-                        if context.dim() == 3:
-                            weight_mask[:, :text_len, :] *= self.text_weight_multiplier
-                        elif context.dim() == 2:
-                            weight_mask[:text_len, :] *= self.text_weight_multiplier
-                        context = context * weight_mask
-                    return original_fn(x, context, context_lens, *args, **kwargs)
-                return hooked_forward
-
-            module.forward = make(layer_idx, original_forward)
+            if not self.native:
+                module.forward = self._make_hook(layer_idx, original_forward)
             layer_idx += 1
-        self.logger.info(f"Hooked {layer_idx} cross-attention layers")
+        self.logger.info(f"Hooked {layer_idx} cross-attention layers ({'native schedule' if self.native else 'forward closures'})")
+
+    def _make_hook(self, layer_index, original_fn):
+        def hooked_forward(x, context, context_lens, *args, **kwargs):
+            if (self.use_bagel_context and self.bagel_context is not None
+                    and (self.injection_layers is None or layer_index in self.injection_layers)
+                    and self.config.use_dynamic_text_weight and self.text_weight_multiplier != 1.0
+                    and context is not None):
+                seq_len = context.shape[1] if context.dim() > 1 else context.shape[0]
+                text_len = min(self.config.bagel_sequence_length, seq_len // 2)
+                weight_mask = torch.ones_like(context)
+                if context.dim() == 3:
+                    weight_mask[:, :text_len, :] *= self.text_weight_multiplier
+                elif context.dim() == 2:
+                    weight_mask[:text_len, :] *= self.text_weight_multiplier
+                context = context * weight_mask
+            return original_fn(x, context, context_lens, *args, **kwargs)
+        return hooked_forward
 
     def set_bagel_context(self, bagel_tokens, fusion_alpha=None, injection_layers=None):
         self.bagel_context = self.context_projector(bagel_tokens) if self.context_projector is not None else bagel_tokens
@@ -165,25 +205,39 @@ class Wan22ContextWrapper:
                 module.__dict__.pop("forward", None)
         self.original_forward_methods = {}
 
+    @contextlib.contextmanager
+    def scheduled(self):
+        """The lifetime of the forward counter = one generation (:1851-1876): reset to 0, advanced by every DiT forward of the loop
+        that runs inside, removed afterwards. native: the loop reads it through WanTI2V.text_weight_schedule; otherwise a counting
+        closure is re-assigned as the DiT's `forward`, as in the reference."""
+        self.sampling_step_counter = 0
+        if self.native:
+            self.original_pipeline.text_weight_schedule = _TextWeightSchedule(self)
+        else:
+            original_dit_forward = self.dit_model.forward
+            wrapper_self = self
+
+            def hooked_dit_forward(hidden_states, t, *args, **kw):
+                wrapper_self.set_timestep(wrapper_self.sampling_step_counter)
+                wrapper_self.sampling_step_counter += 1
+                return original_dit_forward(hidden_states, t, *args, **kw)
+
+            self.dit_model.forward = hooked_dit_forward
+        try:
+            yield self
+        finally:
+            if self.native:
+                self.original_pipeline.text_weight_schedule = None
+            else:
+                self.dit_model.__dict__.pop("forward", None)
+            del self.sampling_step_counter
+
     def generate(self, **kwargs):
-        """:1844-1886: wraps the DiT forward with the forward-call counter that drives the text weight."""
+        """:1844-1886: one generation under the forward counter that drives the text weight."""
         if not self.config.use_dynamic_text_weight:
             return self.original_pipeline.generate(**kwargs)
-        self.sampling_step_counter = 0
-        original_dit_forward = self.dit_model.forward
-        wrapper_self = self
-
-        def hooked_dit_forward(hidden_states, t, *args, **kw):
-            wrapper_self.set_timestep(wrapper_self.sampling_step_counter)
-            wrapper_self.sampling_step_counter += 1
-            return original_dit_forward(hidden_states, t, *args, **kw)
-
-        self.dit_model.forward = hooked_dit_forward
-        try:
+        with self.scheduled():
             return self.original_pipeline.generate(**kwargs)
-        finally:
-            self.dit_model.__dict__.pop("forward", None)
-            del self.sampling_step_counter
 
 
 class ContextProjector(torch.nn.Module):
@@ -245,13 +299,14 @@ class ContextProjector(torch.nn.Module):
 class CrossAttentionFusionPipeline:
     """model_pipeline.py:2110-3230, inference side. Components are injected:
 
-        wan_pipeline     a univid_amd WanTI2V (DiT + VAE + text encoder hook-up)          - the hot path
+        wan_pipeline     a univid_amd WanTI2V (DiT + VAE + text encoder hook-up)          - the hot path; the dynamic text weight
+                         rides on it as data (Wan22ContextWrapper native=True): stacked CFG pair + HIP-graph replay stay in use
         bagel_extractor  object with extract_semantic_tokens(text, image) -> [1, L, 3584]  - off the hot path (stub OK)
         context_projector callable tokens -> list[[512, 4096]]                             - off the hot path (stub OK)
     """
 
     def __init__(self, config: CrossAttentionConfig, wan_pipeline: Optional[WanTI2V] = None, bagel_extractor=None,
-                 context_projector: Optional[Callable] = None, save_fn: Optional[Callable] = None):
+                 context_projector: Optional[Callable] = None, save_fn: Optional[Callable] = None, native_text_weight: bool = True):
         self.config = config
         self.logger = logging.getLogger("univid_amd.pipeline")
         if wan_pipeline is None:
@@ -263,7 +318,8 @@ class CrossAttentionFusionPipeline:
         self.lora_manager = LoRAManager(config, self.logger) if getattr(config, "use_lora", False) else None
         self.dit_model = wan_pipeline.model
         self.vae_model = wan_pipeline.vae
-        self.wan_wrapper = Wan22ContextWrapper(wan_pipeline, context_projector, self.logger, config)
+        # native_text_weight=False: the reference's closures on the model's generic path (kept as the comparison the tests and bench use)
+        self.wan_wrapper = Wan22ContextWrapper(wan_pipeline, context_projector, self.logger, config, native=native_text_weight)
         self.save_fn = save_fn
 
     def generate_video_with_bagel_context(self, text: str, image=None, **kwargs):

@@ -193,17 +193,24 @@ class WanCrossAttention(WanSelfAttention):
     part of UniVid's contract: Wan22ContextWrapper finds modules by `__class__.__name__ == 'WanCrossAttention'`
     and replaces `module.forward` with a closure that rescales `context` (model_pipeline.py:1745-1807)."""
 
-    def _context_kv(self, ctx, Lc, batch, kv_key):
+    def _context_kv(self, ctx, Lc, batch, kv_key, out=None):
         """k = norm_k(Wk ctx) [batch*Lc, C] and V^T = (Wv ctx)^T of the embedded context (model.py:170-172). They depend on the
         context and this block's weights only, not on the latent or the timestep, so across the steps of a sampling loop they are
         computed ONCE: `kv_key` identifies the (context generation, sample group) WanModel.forward is running; None = no caching
-        (the reference-signature forward, i.e. also UniVid's text-weight hook, which rescales the context per step)."""
+        (the reference-signature forward, a context under UniVid's dynamic text weight - it changes from forward to forward -, or
+        out=(k, V^T): the caller's own buffers, written in place - the HIP-graph runner's, which its captured attention launches read)."""
         hit = self._kv_cache.get(kv_key) if kv_key is not None else None
         if hit is not None:
             return hit
         C, D = self.dim, self.head_dim
         p = self._prep
         dev = ctx.device
+        if out is not None:
+            kl, vt = out
+            _lib.gemm_bf16(ctx, p["k"].w, p["k"].b, kl, EPI_BF16, M=batch * Lc)
+            _lib.gemm_bf16(ctx, p["v"].w, p["v"].b, vt, EPI_BF16_T, M=batch * Lc)
+            _lib.rmsnorm_rope(kl, kl, self.norm_k.weight, batch * Lc, C, D, self.eps)
+            return kl, vt
         kl = torch.empty(batch * Lc, C, dtype=BF16, device=dev)
         if kv_key is None:
             vt = _vt_scratch("cvt", C, batch, Lc, dev)
@@ -286,7 +293,11 @@ class WanAttentionBlock(nn.Module):
         tab = torch.empty(n_t, 6 * C, dtype=torch.float32, device=dev)
         _lib.call("uv_add_rows_f32", _lib.ptr(self.modulation), _lib.ptr(e0_rows), _lib.ptr(tab), n_t, 6 * C,
                   _lib.stream_ptr())                                                               # model.py:239
-        h = torch.empty(L, C, dtype=BF16, device=dev)
+        # (rows of the block's bf16 activations: L, or L rounded up to whole 256-row tiles for ffn.0 - see below; the pad rows are never
+        # written and their products never read, so they need no zeroing and no scratch that outlives the forward)
+        Lf = _ffn0_rows(L, self.ffn_dim, dev)
+        h_full = torch.empty(Lf, C, dtype=BF16, device=dev)
+        h = h_full[:L]
         # self-attention (model.py:243-247)
         if twin_rows and batch > 1 and sp is None:
             t1 = None if tid is None else tid[:Ls]
@@ -314,15 +325,11 @@ class WanAttentionBlock(nn.Module):
         # FFN (model.py:252-255)
         # ffn.0 on rows rounded up to whole 256-row tiles where the extra tiles ride in the last, partial round of the persistent GEMM
         # (22 880 rows x 14 336 columns: 19.47 -> 19.69 rounds, both 20) instead of a leftover-row launch behind it: the pad rows of the
-        # input are zeros, their outputs are never read (ffn.2 runs on L rows); results unchanged (a row's arithmetic is the same in both kernels)
-        Lf = _ffn0_rows(L, self.ffn_dim, dev)
-        if Lf != L:
-            # (one scratch per stream, like the V^T scratch: concurrent forwards on different streams - and a HIP-graph capture, whose
-            # scratch then lives in the graph's own memory pool - must not share it)
-            h = _zeros_cached(("ffn_in", dev, torch.cuda.current_stream(dev).cuda_stream), (Lf, C), BF16, dev)
+        # input hold whatever the buffer held (rows are independent: nothing of them reaches a row that is read), their outputs are never
+        # read (ffn.2 runs on L rows); results unchanged (a row's arithmetic is the same in both kernels)
         _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=3 * C, scale_off=4 * C, tid=tid)
         mid = torch.empty(Lf, self.ffn_dim, dtype=BF16, device=dev)
-        _lib.gemm_bf16(h, self._prep["ffn0"].w, self._prep["ffn0"].b, mid, EPI_GELU_BF16, M=Lf)
+        _lib.gemm_bf16(h_full, self._prep["ffn0"].w, self._prep["ffn0"].b, mid, EPI_GELU_BF16, M=Lf)
         _lib.gemm_bf16(mid, self._prep["ffn2"].w, self._prep["ffn2"].b, x, EPI_GATE_RESID_F32, M=L,
                        gate=tab[:, 5 * C:], gate_tid=tid)
 
@@ -419,6 +426,22 @@ def _vt_scratch(tag, C, batch, L, device):
     return t
 
 
+def scratch_snapshot():
+    """Identity of every per-stream scratch tensor (before a HIP-graph capture)."""
+    return {k: id(t) for k, t in _zero_cache.items()}
+
+
+def scratch_take_new(snapshot):
+    """Removes - and returns, for the caller to keep alive - the scratch tensors created since `snapshot`: those of a HIP-graph capture
+    live in that graph's private memory pool, and torch's capture stream (part of their cache key) is shared by all captures."""
+    taken = []
+    for k in list(_zero_cache):
+        if snapshot.get(k) != id(_zero_cache[k]):
+            taken.append(_zero_cache.pop(k))
+            _vt_user.pop(k, None)
+    return taken
+
+
 def tensor_version(u):
     """`u._version`, or -1 for a tensor created under torch.inference_mode() (no version counter; such a tensor cannot be written
     in place outside inference mode, and inside a `context_cached()` scope the caller vouches for it)."""
@@ -493,6 +516,7 @@ class WanModel(nn.Module):
         # on around the loop: `with model.context_cached(): ...` (WanTI2V.denoise and bench.py do).
         self.cache_context = False
         self.sp = None   # SeqParallel when Ulysses sequence parallelism is enabled (enable_sequence_parallel)
+        self._text_weight = None  # (per-sample weights, rows, layers | None): set_text_weight
         self.dedup_twins = True   # block 0's self-attention half once for samples that enter with identical rows (the CFG pair); A/B switch
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
 
@@ -582,6 +606,32 @@ class WanModel(nn.Module):
                 self._ctx_cache = None
                 for b in self.blocks:
                     b.cross_attn._kv_cache = {}
+
+    # ---- UniVid's dynamic text weight, native (models/model_pipeline.py:1699-1810) -----------------------------
+    def set_text_weight(self, weights=None, text_len=0, layers=None):
+        """The per-layer cross-attention hook of UniVid's Wan22ContextWrapper (model_pipeline.py:1742-1810) as model state instead of
+        30 re-assigned `forward` closures: in the blocks of `layers` (None = every block; an iterable of block indices = the wrapper's
+        `injection_layers`) the first `text_len` rows of sample i's EMBEDDED context are multiplied by bf16(weights[i]) before that
+        block's K / V projections - exactly `context * weight_mask` of :1787-1797 - for every forward until the next call.
+        weights: one float per sample of the forward's x / context lists (the CFG pair stacked as [cond, uncond] carries the two
+        consecutive values of the wrapper's per-forward counter, :1856-1864); None, or all 1.0, switches it off (the hook's own
+        `text_weight_multiplier != 1.0` test): the forward is then the plain one, with its cached context K / V^T.
+        Because the rest of the forward is untouched, the stacked CFG pair, block 0's shared self-attention half, the fused
+        residual epilogue and (WanTI2V.denoise) the HIP-graph replay all stay in use."""
+        if weights is not None:
+            weights = tuple(float(w) for w in weights)
+            if all(w == 1.0 for w in weights) or int(text_len) <= 0:
+                weights = None
+        self._text_weight = None if weights is None else (weights, int(text_len), None if layers is None else frozenset(int(i) for i in layers))
+
+    def weighted_context(self, ctx_all, idx, tw):
+        """Embedded contexts of the samples `idx` stacked [len(idx) * text_len, C] with sample i's first tw[1] rows scaled by bf16(tw[0][i])."""
+        weights, n_scaled, _ = tw
+        Lc = ctx_all.shape[1]
+        out = torch.empty(len(idx) * Lc, self.dim, dtype=BF16, device=ctx_all.device)
+        for j, i in enumerate(idx):
+            _lib.text_weight_rows(ctx_all[i], out[j * Lc:(j + 1) * Lc], min(n_scaled, Lc) if weights[i] != 1.0 else 0, weights[i])
+        return out
 
     def _embedded_context(self, context):
         """text_embedding of the prompt embeddings, cached across forwards: in a sampling loop the same context tensors come
@@ -684,10 +734,17 @@ class WanModel(nn.Module):
             # every sample of the group and the same token -> timestep map in every sample.
             twin = (self.dedup_twins and B > 1 and par is None and all(xs_in[i] is xs_in[idx[0]] for i in idx) and
                     (tid is None or twin_t))
+            # UniVid's dynamic text weight (set_text_weight): the hooked blocks read the row-scaled context, and compute their K / V^T
+            # of it in this forward (it changes from forward to forward while the schedule runs; the cache holds the plain one)
+            tw = self._text_weight
+            if tw is not None and len(tw[0]) != len(xs_in):
+                raise ValueError(f"set_text_weight was given {len(tw[0])} weight(s); this forward has {len(xs_in)} sample(s)")
+            ctx_w = self.weighted_context(ctx_all, idx, tw) if (tw is not None and any(tw[0][i] != 1.0 for i in idx)) else None
             for li, blk in enumerate(self.blocks):
+                hooked = ctx_w is not None and (tw[2] is None or li in tw[2])
                 if par is None or n:
-                    blk._run(xs, n, e0_rows, tid, (Fp, Hp, Wp), fr, ctx, first_block=(li == 0), batch=B, sp=sp_arg, kv_key=kv_key,
-                             twin_rows=(twin and li == 0))
+                    blk._run(xs, n, e0_rows, tid, (Fp, Hp, Wp), fr, ctx_w if hooked else ctx, first_block=(li == 0), batch=B, sp=sp_arg,
+                             kv_key=None if hooked else kv_key, twin_rows=(twin and li == 0))
                 else:   # a rank without tokens still takes part in the self-attention exchanges
                     blk.self_attn._self_attn_sp(xs.new_empty(0, C).to(BF16), 0, (Fp, Hp, Wp), fr, xs, None, None, B, sp_arg)
             yh = self.head._run(xs, B * n, e_rows, tid) if B * n else xs.new_empty(0, self.head.head.out_features)

@@ -20,7 +20,8 @@ import torch
 
 from .fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
 from .fm_solvers_unipc import FlowUniPCMultistepScheduler
-from .model import WanModel, _ensure_prepared, tensor_version
+from .. import _lib
+from .model import WanModel, _ensure_prepared
 
 
 def masks_like(tensor, zero=False, generator=None, p=0.2):
@@ -102,15 +103,18 @@ class _GraphedPair:
     textimage2video.py:573 - which `WanModel.forward(..., t_rows=)` takes instead of the per-token tensor). Every kernel is the
     one the eager path launches, in the same order: outputs are bit-identical.
 
-    What changes from GENERATION to generation is the prompt. The step-constant context work (text_embedding, every block's
-    cross-attention K / V^T of it) lives in buffers the RUNNER owns - copies of what the eager warm-up forward left in WanModel's
-    context cache, installed in that cache for the duration of the capture only - and `refresh()` recomputes them IN PLACE for new
-    prompt embeddings (two small GEMMs + a norm + two copies per block: ~3 ms at TI2V-5B size). So one capture per (latent shape,
-    mode, prepared weights) serves every prompt: a new prompt costs no recapture (0.4 s at 49 frames, 1 s at 121: measured,
-    tools/diag/graph_capture_cost.py), and a prompt buffer refilled in place under torch.inference_mode() - invisible to any
-    identity / version key - cannot go stale, because WanTI2V.denoise refreshes at the start of every call (round-3 advisor finding).
+    What changes from GENERATION to generation is the prompt, and - under UniVid's dynamic text weight - what changes during the
+    first steps of a generation is the scale of the prompt's first rows (model_pipeline.py:1699-1810). Both are context work: the
+    embedded context and every block's cross-attention K / V^T of it live in buffers the RUNNER owns, which its captured attention
+    launches read, and `apply()` recomputes them IN PLACE (two small GEMMs + a norm per block, written straight into the buffers:
+    ~3 ms for all 30 blocks at TI2V-5B size) whenever the prompt (`refresh`, at the start of every denoise, unconditionally - an
+    identity / version key can be fooled by a freed-and-reallocated address, round-4 advisor finding) or a block's text weight
+    differs from what its buffers hold. So one capture per (latent shape, mode, prepared weights) serves every prompt and every text-weight
+    schedule: no recapture (0.4 s at 49 frames, 1 s at 121), and once the schedule has reached w = 1 (after
+    int(total_sampling_steps * ratio) forwards) a step is the plain replay, bit for bit.
     """
     def __init__(self, model, latent, context, context_null, seq_len, i2v_mask, key=None):
+        from . import model as _m
         dev = latent.device
         self.key = key
         L = seq_len
@@ -122,62 +126,107 @@ class _GraphedPair:
         # here is allowed; the static buffers below are normal tensors, which inference-mode code may write in place.
         # Capture and replay run with the latent's device current: torch's capture stream belongs to the current device, and the
         # kernels follow the device of their tensors (a model on cuda:1 in a process whose current device is cuda:0).
-        with torch.inference_mode(False), torch.no_grad(), torch.cuda.device(dev), model.context_cached():
-            self.lat = torch.empty(latent.shape, dtype=latent.dtype, device=dev)
-            n_t = 1 if i2v_mask is None else 2
-            self.tvals = torch.zeros(n_t, dtype=torch.float32, device=dev)
-            if i2v_mask is None:
-                tid = None
-            else:   # mask 0 (first latent frame) -> row 0 (timestep 0), mask 1 -> row 1 (timestep t); padding tokens never exist here
-                one = i2v_mask.to(torch.int32)
-                tid = torch.cat([one, one]).contiguous()
-            ctx = [context[0], context_null[0]]
-            self.lat.copy_(latent)
-            # eager warm-up on the capture inputs: weight preparation, context cache, scratch buffers, function attributes
-            model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid, True))
-            torch.cuda.synchronize(dev)
-            # runner-owned copies of the context's cross-attention K / V^T, visible to the model's cache lookups during the capture only
-            kvk = (model._ctx_gen, (0, 1))
-            self.kv, theirs = [], []
-            for b in model.blocks:
-                kl, vt = b.cross_attn._kv_cache[kvk]
-                self.kv.append((kl.clone(), vt.clone()))
-                theirs.append((kl, vt))
-                b.cross_attn._kv_cache[kvk] = self.kv[-1]
-            self.keep = (model._ctx_cache, ctx)       # (the embedded contexts the captured `cat` reads; its result is unused on a cache hit)
-            self.graph = torch.cuda.CUDAGraph()
-            try:
-                with torch.cuda.graph(self.graph):
-                    self.out = model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid, True))
-            finally:
-                for b, own in zip(model.blocks, theirs):
-                    if kvk in b.cross_attn._kv_cache:
-                        b.cross_attn._kv_cache[kvk] = own
-        self.ctx_ids = self._ids(context, context_null)
+        tw, model._text_weight = model._text_weight, None      # the capture is the PLAIN forward; weights arrive through apply()
+        try:
+            with torch.inference_mode(False), torch.no_grad(), torch.cuda.device(dev), model.context_cached():
+                self.lat = torch.empty(latent.shape, dtype=latent.dtype, device=dev)
+                n_t = 1 if i2v_mask is None else 2
+                self.tvals = torch.zeros(n_t, dtype=torch.float32, device=dev)
+                if i2v_mask is None:
+                    tid = None
+                else:   # mask 0 (first latent frame) -> row 0 (timestep 0), mask 1 -> row 1 (timestep t); padding tokens never exist here
+                    one = i2v_mask.to(torch.int32)
+                    tid = torch.cat([one, one]).contiguous()
+                self.tid = tid          # the captured kernels read it on every replay: it has to live as long as the graph (until round 5 it was a
+                                        # local - freed after the capture, its memory handed to the next allocation; found as a GPU memory fault)
+                ctx = [context[0], context_null[0]]
+                self.lat.copy_(latent)
+                # eager warm-up on the capture inputs: weight preparation, context cache, scratch buffers, function attributes
+                model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid, True))
+                torch.cuda.synchronize(dev)
+                # runner-owned copies of the context's cross-attention K / V^T, visible to the model's cache lookups during the capture only
+                kvk = (model._ctx_gen, (0, 1))
+                self.kv, theirs = [], []
+                for b in model.blocks:
+                    kl, vt = b.cross_attn._kv_cache[kvk]
+                    self.kv.append((kl.clone(), vt.clone()))
+                    theirs.append((kl, vt))
+                    b.cross_attn._kv_cache[kvk] = self.kv[-1]
+                emb = model._ctx_cache[2]
+                self.emb = torch.cat([emb[0], emb[1]], 0)   # [2 * text_len, C] bf16: what the K / V projections read (own copy)
+                self.keep = (model._ctx_cache, ctx)       # (the embedded contexts the captured `cat` reads; its result is unused on a cache hit)
+                self.graph = torch.cuda.CUDAGraph()
+                # scratch the forward caches per stream (V^T tiles): tensors born during the capture live in THIS graph's memory pool and
+                # torch's capture stream is shared by all captures, so they must neither be found by a later capture (which would bake an
+                # address of this pool into another graph) nor outlive this runner in a global cache (round-4 advisor finding)
+                snap = _m.scratch_snapshot()
+                try:
+                    with torch.cuda.graph(self.graph):
+                        self.out = model([self.lat, self.lat], None, ctx, L, t_rows=(self.tvals, tid, True))
+                finally:
+                    self.scratch = _m.scratch_take_new(snap)
+                    for b, own in zip(model.blocks, theirs):
+                        if kvk in b.cross_attn._kv_cache:
+                            b.cross_attn._kv_cache[kvk] = own
+        finally:
+            model._text_weight = tw
+        self.state = [(1.0, 1.0)] * len(self.kv)     # per block: the (cond, uncond) text weights its K / V^T buffers were computed with
+        self._scaled = None                          # ((w_cond, w_uncond), rows) -> the row-scaled embedded context of the current prompt
 
-    @staticmethod
-    def _ids(context, context_null):
-        from .model import tensor_version
-        return tuple((u.data_ptr(), tensor_version(u), tuple(u.shape)) for u in (context[0], context_null[0]))
+    def __del__(self):
+        # the graph (and its memory pool) must not be destroyed under a replay that is still running: a generation returns without
+        # synchronising, and the next one - another latent shape - drops this runner right away (found by tests/test_pipeline_path.py:
+        # the process aborted inside the drop)
+        try:
+            torch.cuda.synchronize(self.dev)
+        except Exception:
+            pass
 
-    def refresh(self, context, context_null, force=False):
-        """The runner's context buffers recomputed in place for these prompt embeddings. Skipped only when the SAME version-counted
-        tensors come back unchanged; tensors without a version counter (torch.inference_mode) are always recomputed."""
-        ids = self._ids(context, context_null)
-        if not force and ids == self.ctx_ids and all(v != -1 for _, v, _ in ids):
-            return
+    def refresh(self, context, context_null):
+        """New prompt embeddings: the embedded context is recomputed and every block's K / V^T marked stale (recomputed in place by the
+        next apply()). Called at the start of every denoise that reuses the runner; there is no 'unchanged' shortcut on purpose."""
         m = self.model
         with torch.inference_mode(False), torch.no_grad(), torch.cuda.device(self.dev):
             emb = m.embed_context([context[0], context_null[0]])          # [2, text_len, C] bf16
-            cat = torch.cat([emb[0], emb[1]], 0)
-            for blk, (kl_own, vt_own) in zip(m.blocks, self.kv):
-                kl, vt = blk.cross_attn._context_kv(cat, m.text_len, 2, None)      # kv_key None: recomputed (V^T in the shared scratch)
-                kl_own.copy_(kl)
-                vt_own.copy_(vt)
-        self.ctx_ids = ids
+            self.emb = torch.cat([emb[0], emb[1]], 0)
+        self.state = [None] * len(self.kv)
+        self._scaled = None
 
-    def __call__(self, latent, t):
+    def apply(self, text_weight=None):
+        """Brings every block's K / V^T buffers to the text weight of the coming forward pair: text_weight = None (plain) or
+        ((w_cond, w_uncond), rows, layers | None) as WanModel.set_text_weight takes it. Blocks whose buffers already hold the wanted
+        weights are left alone: in the plain loop this is 30 tuple comparisons per step."""
+        plain = (1.0, 1.0)
+        w, rows, layers = plain, 0, None
+        if text_weight is not None:
+            w, rows, layers = (float(text_weight[0][0]), float(text_weight[0][1])), int(text_weight[1]), text_weight[2]
+        active = w != plain and rows > 0
+
+        def want(li):
+            return w if (active and (layers is None or li in layers)) else plain
+        stale = [li for li in range(len(self.kv)) if self.state[li] != want(li)]
+        if not stale:
+            return 0
+        m = self.model
+        Lc = m.text_len
+        with torch.inference_mode(False), torch.no_grad(), torch.cuda.device(self.dev):
+            for li in stale:
+                hooked = want(li) != plain
+                src = self.emb
+                if hooked:
+                    if self._scaled is None or self._scaled[0] != (w, rows):
+                        sc = torch.empty_like(self.emb)
+                        for j in range(2):
+                            _lib.text_weight_rows(self.emb[j * Lc:(j + 1) * Lc], sc[j * Lc:(j + 1) * Lc], min(rows, Lc) if w[j] != 1.0 else 0, w[j])
+                        self._scaled = ((w, rows), sc)
+                    src = self._scaled[1]
+                m.blocks[li].cross_attn._context_kv(src, Lc, 2, None, out=self.kv[li])
+                self.state[li] = w if hooked else plain
+        return len(stale)
+
+    def __call__(self, latent, t, text_weight=None):
         with torch.cuda.device(self.dev):
+            self.apply(text_weight)
             self.lat.copy_(latent)
             self.tvals[-1:].fill_(t)         # the value travels as a kernel argument (no host buffer to race with); row 0 stays 0 for i2v
             self.graph.replay()
@@ -205,6 +254,7 @@ class WanTI2V:
         self.sp_size = 1
         self.cfgp = None
         self._runner = None      # cached _GraphedPair (HIP graph of the CFG pair's forward) of the last graph-mode denoise
+        self.text_weight_schedule = None   # object with next_pair() / rows(text_len) / layers: UniVid's dynamic text weight, native
         self.sample_neg_prompt = config.sample_neg_prompt
         self.text_encoder = text_encoder
         self.vae = vae
@@ -306,8 +356,11 @@ class WanTI2V:
         c, f, h, w = latent.shape
         seq_len = math.ceil((h * w) / (self.patch_size[1] * self.patch_size[2]) * f / self.sp_size) * self.sp_size
         base_mask = mask2[0][0][:, ::2, ::2].flatten()
-        plain = (self.cfgp is None and self.sp_size == 1 and "forward" not in self.model.__dict__ and
-                 not any("forward" in b.cross_attn.__dict__ for b in self.model.blocks))
+        foreign = "forward" in self.model.__dict__ or any("forward" in b.cross_attn.__dict__ for b in self.model.blocks)
+        plain = self.cfgp is None and self.sp_size == 1 and not foreign
+        # the native text-weight schedule (set by univid_amd.model_pipeline.Wan22ContextWrapper.generate for the length of one generation)
+        # rides on the plain path; with re-assigned forwards (somebody else's hooks) the closures own the context and it stays out
+        tws = None if foreign else self.text_weight_schedule
         n_tok = base_mask.numel()
         if graph is None:
             graph = plain and graph_by_default(n_tok)
@@ -326,9 +379,25 @@ class WanTI2V:
                 runner = self._runner = _GraphedPair(self.model, latent, context, context_null, seq_len, base_mask if i2v else None, key)
             else:
                 runner.refresh(context, context_null)
+        try:
+            return self._steps(sched, timesteps, latent, context, context_null, guide_scale, z, mask2, base_mask, seq_len, record, runner, tws)
+        finally:
+            if tws is not None and hasattr(self.model, "set_text_weight"):
+                self.model.set_text_weight(None)
+
+    def _steps(self, sched, timesteps, latent, context, context_null, guide_scale, z, mask2, base_mask, seq_len, record, runner, tws):
+        dev = self.device
+        i2v = z is not None
         for t in timesteps:
+            tw = None
+            if tws is not None:
+                # UniVid's dynamic text weight, native (model_pipeline.py:1699-1810, 1844-1886): the wrapper's counter advances once per
+                # DiT forward, the cond forward first (:1856-1864, textimage2video.py:380-385) - the stacked CFG pair carries both values
+                wc, wu = tws.next_pair()
+                if wc != 1.0 or wu != 1.0:
+                    tw = ((wc, wu), tws.rows(self.model.text_len), tws.layers)
             if runner is not None:
-                cond, uncond = runner(latent, float(t))
+                cond, uncond = runner(latent, float(t), tw)
                 res = sched.step_cfg(cond.unsqueeze(0), uncond.unsqueeze(0), guide_scale, t, latent.unsqueeze(0),
                                      want_noise_pred=record is not None)
                 if record is not None:
@@ -344,10 +413,16 @@ class WanTI2V:
             temp_ts = base_mask * ts                                                   # :373
             temp_ts = torch.cat([temp_ts, temp_ts.new_ones(seq_len - temp_ts.size(0)) * ts])
             tvec = temp_ts.unsqueeze(0)
+            if tws is not None:
+                if tw is None:
+                    self.model.set_text_weight(None)
+                else:      # (CFG parallel: this rank runs ONE of the pair's forwards and takes that forward's value of the counter)
+                    self.model.set_text_weight(tw[0] if self.cfgp is None else (tw[0][self.cfgp.rank],), tw[1], tw[2])
             if self.cfgp is not None:
                 if "forward" in self.model.__dict__:
-                    raise NotImplementedError("the per-forward text-weight counter (model_pipeline.py:1856-1868) counts two forwards "
-                                              "per step on one rank; it cannot be combined with CFG parallelism")
+                    raise NotImplementedError("a re-assigned model.forward (the reference's per-forward text-weight counter, model_pipeline.py"
+                                              ":1856-1868) counts two forwards per step on one rank; with CFG parallelism use the native "
+                                              "schedule (Wan22ContextWrapper(native=True)): each rank takes its own value of the pair")
                 mine = context if self.cfgp.rank == 0 else context_null
                 cond, uncond = self.cfgp.exchange(self.model([latent], t=tvec, context=mine, seq_len=seq_len)[0])
             elif "forward" in self.model.__dict__:
