@@ -80,6 +80,72 @@ def test_eight_rank_sharding_uneven_shards_and_gather(n_samples):
     assert max(sizes) - min(sizes) <= 1 and sum(sizes) == n_samples
 
 
+class WanCrossAttention(torch.nn.Module):          # found by CLASS NAME (model_pipeline.py:1745)
+    def forward(self, x, context, context_lens):
+        return x
+
+
+class _SchedPipe:
+    """Stands in for WanTI2V on the pipeline path: `denoise` consumes the native text-weight schedule exactly as WanTI2V._steps does
+    (one (cond, uncond) pair of weights per step) and folds every weight into the result, so a wrong / shared / not-restarted forward
+    counter changes the latent."""
+
+    def __init__(self):
+        self.model = torch.nn.Sequential(WanCrossAttention(), WanCrossAttention())
+        self.text_weight_schedule = None
+
+    def denoise(self, noise, ctx, ctx_null, steps, shift, gs):
+        out = noise * 2.0 + ctx[0].sum()
+        for k in range(steps):
+            wc, wu = self.text_weight_schedule.next_pair() if self.text_weight_schedule is not None else (1.0, 1.0)
+            out = out + (k + 1) * (wc * 10.0 + wu)
+        return out
+
+
+def _pipeline_path_worker(rank, world, port, n_samples, q):
+    import logging
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from univid_amd.model_pipeline import CrossAttentionConfig, Wan22ContextWrapper
+        pipe = _SchedPipe()
+        cfg = CrossAttentionConfig(use_dynamic_text_weight=True, total_sampling_steps=10, text_weight_transition_ratio=0.5, text_weight_schedule="linear")
+        wr = Wan22ContextWrapper(pipe, None, logging.getLogger("t"), cfg)
+        wr.set_bagel_context(torch.zeros(1, 2, 2))
+        g = torch.Generator().manual_seed(0)
+        noises = [torch.randn(4, 2, 3, 3, generator=g) for _ in range(n_samples)]
+        ctx = [[torch.full((2, 2), float(i))] for i in range(n_samples)]
+        ctxn = [[torch.zeros(1, 2)] for _ in range(n_samples)]
+        out = parallel.denoise_batch(pipe, noises, ctx, ctxn, 4, 5.0, 5.0, wrapper=wr)
+        # single-process expectation: every sample starts its own counter at 0 (w = 1.3 - 0.3 * c / 5 for c < 5, else 1.0)
+        w = [wr._calculate_text_weight(c) for c in range(8)]
+        bump = sum((k + 1) * (w[2 * k] * 10.0 + w[2 * k + 1]) for k in range(4))
+        expect = [n * 2.0 + 4.0 * i + bump for i, n in enumerate(noises)]
+        ok = len(out) == n_samples and all(torch.allclose(a, b, rtol=0, atol=1e-4) for a, b in zip(out, expect))
+        ok &= w[0] == 1.3 and w[5] == 1.0 and pipe.text_weight_schedule is None and not hasattr(wr, "sampling_step_counter")
+        ok &= all("forward" not in m.__dict__ for m in pipe.model)            # native: nothing re-assigned
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_denoise_batch_on_the_pipeline_path():
+    """parallel.denoise_batch(wrapper=): the replicas run UniVid's pipeline path - each sample one generation under its rank's own
+    forward counter, restarted per sample (3 samples on 2 ranks: rank 0 runs two in a row)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipeline_path_worker, args=(r, 2, port, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
 def test_seed_depends_on_global_index_only():
     assert parallel.sample_seed(42, 5) == 47
     assert [parallel.sample_seed(42, i) for i in range(*parallel.shard_range(8, 3, 4))] == [48, 49]

@@ -66,13 +66,25 @@ def gather_latents(local: Sequence[torch.Tensor], n_samples: int) -> List[torch.
 
 
 def denoise_batch(pipe, noises: Sequence[torch.Tensor], contexts, contexts_null, sampling_steps, shift, guide_scale,
-                  gather=True):
+                  gather=True, wrapper=None):
     """Shards `noises` (one latent per sample) over the ranks, denoises the local slice with `pipe.denoise`, and
-    (optionally) all-gathers the final latents."""
+    (optionally) all-gathers the final latents.
+
+    wrapper: this rank's univid_amd.model_pipeline.Wan22ContextWrapper around `pipe` - UniVid's pipeline path (model_pipeline.py
+    :1844-1886): every sample is one generation, i.e. runs inside `wrapper.scheduled()`, whose forward counter (the dynamic text
+    weight's clock) belongs to this rank's wrapper and restarts with every sample - so a sample's result does not depend on which rank
+    ran it or on what that rank ran before."""
     rank, ws = world()
     n = len(noises)
     lo, hi = shard_range(n, rank, ws)
-    local = [pipe.denoise(noises[i], contexts[i], contexts_null[i], sampling_steps, shift, guide_scale) for i in range(lo, hi)]
+
+    def one(i):
+        if wrapper is not None and wrapper.config.use_dynamic_text_weight:
+            with wrapper.scheduled():
+                return pipe.denoise(noises[i], contexts[i], contexts_null[i], sampling_steps, shift, guide_scale)
+        return pipe.denoise(noises[i], contexts[i], contexts_null[i], sampling_steps, shift, guide_scale)
+
+    local = [one(i) for i in range(lo, hi)]
     return gather_latents(local, n) if gather else local
 
 
