@@ -327,43 +327,56 @@ _VAE_DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (f32 accumulate)",
               "bf16x6": "f32 operands, products on the bf16 MFMA by exact 3-way splitting (6 passes, error < 2^-26 per product), f32 accumulate"}
 
 
-def vae_metrics(device, precision, encode=True):
+def vae_metrics(device, precision, encode=True, reps=3):
     """BASELINE.json's second metric (config 4): Wan2.2 VAE on a 49-frame 720x1280 clip, random-init weights: encode
     [3,49,720,1280] -> [48,13,45,80] (vae2_2.py:783-810) and decode back (:812-839). precision 'fp32' = exact f32 MFMA, the
-    reference's dtype (vae2_2.py:897) and the HEADLINE; 'bf16x3' = opt-in split-bf16 3-pass convolutions (drops the lo*lo term:
-    narrower than fp32, inside rtol 1e-3 / atol 1e-4 of it, tests/test_gpu_parity.py) - reported under its own key only;
-    'bf16x6' = the f32 operands split exactly into three bf16 planes in registers, six bf16 MFMA passes, f32 accumulate: as close
-    to an fp64 convolution as the f32 MFMA kernel (test_conv3d_bf16x6_is_f32_grade) - f32-grade arithmetic on the faster pipe,
-    also under its own key (the headline stays the f32 MFMA).
-    GB/s = fp32 RGB bytes (out for decode, in for encode) / time."""
+    reference's dtype (vae2_2.py:897); 'f16x3' = Wan2_2_VAE's default (f32-grade in 3 fp16 passes); 'bf16x6' = the f32 operands split
+    exactly into three bf16 planes, six passes; 'bf16x3' = two-way bf16 split (drops lo*lo: ~1e-5) - each under its own key.
+    Timing (round-4 verdict: the decode's wall clock held allocator stalls): ONE full-size warm-up call fills the VAE's workspace arena
+    (WanVAE_._arena), then `reps` timed calls, each bracketed by a device synchronise; `seconds` = their MEDIAN, min / max beside it,
+    and the number of device allocations (hipMalloc calls of torch's allocator) the timed calls caused - 0 means a call's wall time is
+    its kernel time. GB/s = fp32 RGB bytes (out for decode, in for encode) / median time."""
     from univid_amd.wan.vae2_2 import Wan2_2_VAE
     vae = Wan2_2_VAE(device=device, seed=0, precision=precision)
     g = torch.Generator(device=device).manual_seed(7)
     res = {}
+
+    def timed(fn):
+        out = fn()                                               # full-size warm-up: arena, kernel load, split weights
+        torch.cuda.synchronize()
+        a0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
+        ts = []
+        for _ in range(reps):
+            del out
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        allocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - a0
+        ts.sort()
+        return out, ts[len(ts) // 2], ts, allocs
+
     with torch.no_grad():
         z = torch.randn(48, 13, 45, 80, device=device, generator=g)
-        vae.decode([z[:, :2].contiguous()])                      # warm-up (allocations, kernel load)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        v = vae.decode([z])[0]
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        v, dt, ts, allocs = timed(lambda: vae.decode([z])[0])
         tf = VAE_DECODE_TFLOP / dt
         res["decode"] = {"metric": "vae_decode_GBps", "value": round(v.numel() * 4 / dt / 1e9, 4), "unit": "GB/s", "seconds": round(dt, 3),
+                         "seconds_min": round(ts[0], 3), "seconds_max": round(ts[-1], 3), "max_over_min": round(ts[-1] / ts[0], 4), "timed_calls": reps,
+                         "device_allocs_in_timed_calls": allocs,
                          "clip": "49x720x1280 RGB from latent [48,13,45,80]", "dtype": _VAE_DTYPE[precision],
                          "tflops": round(tf, 1), **_vae_bound(precision, tf), "finite": bool(torch.isfinite(v).all().item())}
         if encode:
             video = v.clamp_(-1, 1)                              # a [3,49,720,1280] clip in [-1, 1]: the decode's own output
-            vae.encode([video[:, :5].contiguous()])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            zz = vae.encode([video])[0]
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            zz, dt, ts, allocs = timed(lambda: vae.encode([video])[0])
             tf = VAE_ENCODE_TFLOP / dt
             res["encode"] = {"metric": "vae_encode_GBps", "value": round(video.numel() * 4 / dt / 1e9, 4), "unit": "GB/s", "seconds": round(dt, 3),
+                             "seconds_min": round(ts[0], 3), "seconds_max": round(ts[-1], 3), "max_over_min": round(ts[-1] / ts[0], 4), "timed_calls": reps,
+                             "device_allocs_in_timed_calls": allocs,
                              "clip": "49x720x1280 RGB -> latent " + str(list(zz.shape)), "dtype": _VAE_DTYPE[precision],
                              "tflops": round(tf, 1), **_vae_bound(precision, tf), "finite": bool(torch.isfinite(zz).all().item())}
+    del vae
+    torch.cuda.empty_cache()
     return res
 
 
@@ -615,7 +628,7 @@ def main():
             traffic = None   # HBM-side bytes per launch: PMC counters cannot be read in-process; taken from the committed passes
             try:
                 traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["self_attention_L11440"]["traffic_bytes_per_launch"]
-                traffic *= prof["uv_flash_attn_bf16"][0][2] / self_attn_flops(L_TOKENS, cfg["dim"])   # samples per launch
+                traffic *= launch_flops / self_attn_flops(L_TOKENS, cfg["dim"])   # samples per launch of the launches `achieved` is computed from
             except Exception:
                 pass
             if args.shape != "A":
@@ -689,9 +702,9 @@ def main():
             out["vae_decode"], out["vae_encode"] = x3["decode"], x3["encode"]
             out["vae_precision_note"] = ("vae_decode / vae_encode = Wan2_2_VAE's default precision 'f16x3'; vae_*_fp32 = the exact-f32 MFMA mode "
                                          "(the reference's dtype, the headline of rounds 1-3); tensors in and out are fp32 in every mode")
-            f32 = vae_metrics(device, "fp32")
+            f32 = vae_metrics(device, "fp32", reps=2)
             out["vae_decode_fp32"], out["vae_encode_fp32"] = f32["decode"], f32["encode"]
-            x6 = vae_metrics(device, "bf16x6")
+            x6 = vae_metrics(device, "bf16x6", reps=2)
             out["vae_decode_bf16x6"], out["vae_encode_bf16x6"] = x6["decode"], x6["encode"]
             out["vae_decode_bf16x3"] = vae_metrics(device, "bf16x3", encode=False)["decode"]
         if world == 1 and not args.no_vae and not args.layers and args.shape == "A":

@@ -310,6 +310,44 @@ def test_flash_attention_key_tile_edges(Lk):
     assert (out[:Lq].float() - 1).abs().max() <= 2 ** -7
 
 
+@pytest.mark.parametrize("Lq,Lk", [(300, 300), (2200, 2200), (1000, 77), (2304, 2304)])
+def test_flash_attention_nan_and_masked_tile_behaviour_is_pinned(Lq, Lk):
+    """attention.hip is built with -fno-honor-nans (univid_amd/build.py: removes the canonicalising v_max in front of every fmaxf on MFMA
+    outputs). Round-4 advisor: a promise about NaNs under that flag holds for one compiler's codegen only - so it is pinned HERE, for all
+    three kernels (short-key fwd3, generic, long-key fwd12): (a) a NaN in ONE query row poisons exactly that row (all heads it touches) and
+    leaves every other row bit-identical to the clean run; (b) a NaN in ONE key poisons every row of that head and leaves the other head
+    bit-identical; (c) the masked tail of a ragged last key tile (scores at -inf, possibly a whole 32-key half) yields finite rows - also when
+    the padding columns of V^T hold huge values; (d) +-inf-free inputs never produce a NaN. A compiler that folds these paths fails here."""
+    H, D = 2, 128
+    C = H * D
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q, k, v = (torch.randn(n, C, generator=g).to(BF16).to(DEV) for n in (Lq, Lk, Lk))
+    vt = torch.zeros(C, (Lk + 63) // 64 * 64, dtype=BF16, device=DEV)
+    vt[:, :Lk] = v.t()
+    vt[:, Lk:] = 3.0e38                                                      # (c): finite garbage in the padding columns
+
+    def run(q_, k_):
+        out = torch.empty(Lq, C, dtype=BF16, device=DEV)
+        L().flash_attn(q_, k_, vt, out, Lq, Lk, H, D, 1.0 / math.sqrt(D))
+        return out.float()
+
+    clean = run(q, k)
+    assert torch.isfinite(clean).all()                                       # (c), (d)
+    qn = q.clone()
+    qn[Lq // 3, 5] = float("nan")                                            # head 0 of one row
+    got = run(qn, k)
+    row = got[Lq // 3]
+    assert torch.isnan(row[:D]).all(), "a NaN query must poison its row of that head"
+    keep = torch.ones(Lq, dtype=torch.bool, device=DEV)
+    keep[Lq // 3] = False
+    assert torch.equal(got[keep], clean[keep]) and torch.equal(row[D:], clean[Lq // 3, D:])
+    kn = k.clone()
+    kn[Lk // 2, D + 7] = float("nan")                                        # head 1 of one key
+    got = run(q, kn)
+    assert torch.isnan(got[:, D:]).all(), "a NaN key must poison every row of its head"
+    assert torch.equal(got[:, :D], clean[:, :D])
+
+
 @pytest.mark.parametrize("Lk", [2048, 2104, 2112, 2184])
 def test_flash_attention_long_key_kernel(Lk):
     """Lk >= 2048 selects the 12-wave-workgroup kernel (384 queries per workgroup, K / V^T tiles shared by 12 waves): even / odd tile
@@ -1821,6 +1859,44 @@ def test_vae_list_api_and_state_is_reset_between_calls():
     assert torch.equal(a[1], b[0]), "feature caches must be cleared between clips (clear_cache, vae2_2.py:813,838)"
     assert_f32_close(a[0], g["dec_out_0"])
     assert_f32_close(e[0], g["enc_out_0"])
+
+
+def test_vae_workspace_arena_repeat_calls_allocate_nothing_on_the_device():
+    """WanVAE_._arena: a decode / encode draws everything but its result from a memory pool the VAE owns. After one call at a clip shape,
+    repeat calls at that shape cause NO device allocation (torch's num_device_alloc = hipMalloc calls) - also after the rest of the
+    process churned the shared pool and called empty_cache() in between - and give the same bits; a model without the arena
+    (use_arena = False) gives the same bits too. Also: the result tensor is the caller's (it survives dropping the VAE)."""
+    import gc
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    vae = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=3)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    z = torch.randn(48, 5, 6, 10, device=DEV, generator=g)
+    with torch.no_grad():
+        v0 = vae.decode([z])[0]
+        e0 = vae.encode([v0.clamp(-1, 1)])[0]
+        torch.cuda.synchronize()
+        junk = [torch.empty(3 << 20, device=DEV) for _ in range(8)]           # churn in the shared pool
+        del junk
+        gc.collect()
+        torch.cuda.empty_cache()
+        vc = v0.clamp(-1, 1)
+        n1 = torch.cuda.memory_stats(DEV)["num_device_alloc"]
+        v1 = vae.decode([z])[0]
+        e1 = vae.encode([vc])[0]
+        torch.cuda.synchronize()
+        n2 = torch.cuda.memory_stats(DEV)["num_device_alloc"]
+    assert torch.equal(v0, v1) and torch.equal(e0, e1)
+    # (the two RESULTS are the caller's tensors and come from the shared pool, which empty_cache() just emptied: at most one segment each)
+    assert n2 - n1 <= 2, f"repeat VAE calls allocated on the device: {n2 - n1} hipMalloc(s) for two result tensors"
+    plain = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=3)
+    plain.model.use_arena = False
+    with torch.no_grad():
+        v2 = plain.decode([z])[0]
+    assert torch.equal(v0, v2)
+    del vae, plain
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert torch.isfinite(v1).all() and torch.equal(v1, v2)
 
 
 def test_vae_pass_length_does_not_change_the_result():

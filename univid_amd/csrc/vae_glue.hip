@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void vae_rms_silu_kernel(const float* in, long
 extern "C" int uv_vae_rms_silu(const float* in, long ld_in, const float* gamma, float* out, long ld_out, long P, int C,
                                int do_silu, int split_out, void* stream) {
     UV_CHECK_ARG(in && gamma && out && P > 0, "uv_vae_rms_silu: bad arguments");
+    UV_CHECK_ARG(split_out >= 0 && split_out <= 2, "uv_vae_rms_silu: split_out must be 0 (f32 rows), 1 (bf16 pieces) or 2 (fp16 pieces), got %d", split_out);
     UV_CHECK_ARG(!split_out || C % 32 == 0, "uv_vae_rms_silu: split output needs C %% 32 == 0 (C=%d)", C);
     UV_CHECK_ARG(C % 4 == 0 && C <= 2048 && ld_in % 4 == 0 && ld_out % 4 == 0, "uv_vae_rms_silu: C=%d unsupported", C);
     const dim3 block(256);

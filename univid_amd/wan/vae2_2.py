@@ -13,6 +13,7 @@ chunks instead of one: same values, larger launches); the per-convolution featur
 per convolution that is prepended to each pass's input.
 Everything is fp32 like the reference (`dtype=torch.float`, vae2_2.py:897, 1028, 1042). No eager fallback.
 """
+import contextlib
 import logging
 import math
 from typing import List
@@ -534,6 +535,8 @@ class WanVAE_(nn.Module):
         self.conv2 = CausalConv3d(z_dim, z_dim, 1)
         self.decoder = Decoder3d(dec_dim, z_dim, dim_mult, num_res_blocks, attn_scales, self.temperal_upsample, dropout)
         self._engine = None
+        self._pool = None             # workspace arena (torch.cuda.MemPool) of the engine: see _arena
+        self.use_arena = True
         self.precision = "f16x3"      # default arithmetic of the convolutions (prepare()); 'fp32' = the reference's dtype, exact f32 MFMA
         # Latent frames per decoder pass / 4-frame chunks per encoder pass after the first chunk. The reference streams ONE at a
         # time (vae2_2.py:797-806, 824-835) to bound memory; every layer is time-causal with a 2-frame cache, so longer passes
@@ -544,6 +547,21 @@ class WanVAE_(nn.Module):
 
     def invalidate(self):
         self._engine = None
+        self._pool = None
+
+    def _arena(self):
+        """Workspace arena: everything an encode / decode allocates besides its result - the activations of every layer, the
+        convolutions' cached frames and input rings, the split weights - comes from a memory pool this VAE owns (torch's caching
+        allocator, routed to a private pool for the length of the call). The first call at a (clip shape, precision, frames_per_pass)
+        fills the pool with device allocations; every later call finds its blocks there: no hipMalloc / hipFree inside a decode, whatever
+        the rest of the process (the DiT's loop, an empty_cache() elsewhere) did to the shared pool in between - a decode's wall time is its
+        kernel time (round-4 verdict: 1.73 -> 3.65 s by allocator state). Memory plumbing only; dropped by invalidate() and by the
+        out-of-memory retry."""
+        if not self.use_arena or not hasattr(torch.cuda, "MemPool"):
+            return contextlib.nullcontext()
+        if self._pool is None:
+            self._pool = torch.cuda.MemPool()
+        return torch.cuda.use_mem_pool(self._pool, device=next(self.parameters()).device)
 
     def prepare(self, precision=None):
         """precision: 'fp32' = exact f32 MFMA (the reference's dtype) | 'bf16x6' = the same f32 operands, products on the
@@ -581,7 +599,8 @@ class WanVAE_(nn.Module):
                     raise
                 logging.warning(f"WanVAE_: out of memory at {G} frames per pass, retrying with {G // 2}")
                 G //= 2
-                self._engine.scratch.clear()
+                self._engine = None          # (its cached frames and rings live in the arena)
+                self._pool = None
                 torch.cuda.empty_cache()
 
     def encode(self, x, scale):
@@ -589,22 +608,25 @@ class WanVAE_(nn.Module):
         return self._with_pass_length(self._encode, x, scale)
 
     def _encode(self, G, x, scale):
-        eng = self._eng()
-        eng.reset()
         vid = x[0].contiguous().float()
         F = vid.shape[1]
-        outs = [eng.encoder_chunk(vid, 0, 1, first_chunk=True)]
         n4 = (F - 1) // 4                                                         # 4-frame chunks after the first frame
-        for c0 in range(0, n4, G):
-            g = min(G, n4 - c0)
-            outs.append(eng.encoder_chunk(vid, 1 + 4 * c0, 4 * g, first_chunk=False))
-        out = torch.cat(outs, 0)                                                  # [f, h, w, 2z]
-        y = eng._pointwise(eng.ops[self.conv1], out)                              # 1x1x1, then chunk(2) -> mu
-        f, h, w, _ = y.shape
-        mu = torch.empty(1, self.z_dim, f, h, w, dtype=torch.float32, device=y.device)
-        _lib.call("uv_vae_latent_out", _lib.ptr(y), y.stride(-2), _lib.ptr(scale[0]), _lib.ptr(scale[1]), _lib.ptr(mu), self.z_dim,
-                  f * h * w, _lib.stream_ptr())
-        eng.reset()
+        mu = torch.empty(1, self.z_dim, 1 + n4, vid.shape[2] // 16, vid.shape[3] // 16, dtype=torch.float32, device=vid.device)   # the result: the caller's
+        with self._arena():
+            eng = self._eng()
+            eng.reset()
+            outs = [eng.encoder_chunk(vid, 0, 1, first_chunk=True)]
+            for c0 in range(0, n4, G):
+                g = min(G, n4 - c0)
+                outs.append(eng.encoder_chunk(vid, 1 + 4 * c0, 4 * g, first_chunk=False))
+            out = torch.cat(outs, 0)                                              # [f, h, w, 2z]
+            y = eng._pointwise(eng.ops[self.conv1], out)                          # 1x1x1, then chunk(2) -> mu
+            f, h, w, _ = y.shape
+            assert (f, h, w) == tuple(mu.shape[2:]), ((f, h, w), mu.shape)
+            _lib.call("uv_vae_latent_out", _lib.ptr(y), y.stride(-2), _lib.ptr(scale[0]), _lib.ptr(scale[1]), _lib.ptr(mu), self.z_dim,
+                      f * h * w, _lib.stream_ptr())
+            eng.reset()
+            del outs, out, y
         return mu
 
     def decode(self, z, scale, clamp=True):
@@ -612,24 +634,26 @@ class WanVAE_(nn.Module):
         return self._with_pass_length(self._decode, z, scale)
 
     def _decode(self, G, z, scale):
-        eng = self._eng()
-        eng.reset()
         zz = z[0].contiguous().float()
         Z, f, h, w = zz.shape
-        rows = torch.empty(f, h, w, Z, dtype=torch.float32, device=zz.device)
-        _lib.call("uv_vae_latent_in", _lib.ptr(zz), _lib.ptr(scale[0]), _lib.ptr(scale[1]), _lib.ptr(rows), Z, Z, f * h * w,
-                  _lib.stream_ptr())
-        x = eng._pointwise(eng.ops[self.conv2], rows)                             # conv2 (1x1x1) on all frames
         F = 4 * (f - 1) + 1
-        vid = torch.empty(1, 3, F, 16 * h, 16 * w, dtype=torch.float32, device=zz.device)
-        f0 = 0
-        for i0, i1 in [(0, 1)] + [(i, min(i + G, f)) for i in range(1, f, G)]:
-            y = eng.decoder_chunk(x[i0:i1], first_chunk=(i0 == 0))               # [T, 8h, 8w, 12]
-            T = y.shape[0]
-            _lib.call("uv_vae_video_out", _lib.ptr(y), y.stride(-2), _lib.ptr(vid), F, 8 * h, 8 * w, f0, T, _lib.stream_ptr())
-            f0 += T
-        assert f0 == F
-        eng.reset()
+        vid = torch.empty(1, 3, F, 16 * h, 16 * w, dtype=torch.float32, device=zz.device)      # the result: the caller's, not the arena's
+        with self._arena():
+            eng = self._eng()
+            eng.reset()
+            rows = torch.empty(f, h, w, Z, dtype=torch.float32, device=zz.device)
+            _lib.call("uv_vae_latent_in", _lib.ptr(zz), _lib.ptr(scale[0]), _lib.ptr(scale[1]), _lib.ptr(rows), Z, Z, f * h * w,
+                      _lib.stream_ptr())
+            x = eng._pointwise(eng.ops[self.conv2], rows)                         # conv2 (1x1x1) on all frames
+            f0 = 0
+            for i0, i1 in [(0, 1)] + [(i, min(i + G, f)) for i in range(1, f, G)]:
+                y = eng.decoder_chunk(x[i0:i1], first_chunk=(i0 == 0))           # [T, 8h, 8w, 12]
+                T = y.shape[0]
+                _lib.call("uv_vae_video_out", _lib.ptr(y), y.stride(-2), _lib.ptr(vid), F, 8 * h, 8 * w, f0, T, _lib.stream_ptr())
+                f0 += T
+            assert f0 == F
+            eng.reset()
+            del rows, x, y
         return vid
 
     def init_weights(self, seed=0):
