@@ -48,16 +48,24 @@ def dit_forward_flops(L, cfg, executed=False):
 def hipblaslt_ref(device):
     """The vendor library on the ffn.0 shape (22880 x 14336 x 3072, the one DiT GEMM shape where it is ahead), next to
     uv_gemm_bf16_nt in the SAME run and OUTSIDE the timed region: interleaved rounds, random operands, plain bf16 epilogue.
-    Calibration only - the product path never calls a vendor GEMM."""
+    The uv side runs the launch the PRODUCT runs for this GEMM (WanAttentionBlock._run / _ffn0_rows: the input rows rounded up to whole
+    256-row tiles, 23 040, inside one buffer - 19.69 rounds of the persistent kernel, no leftover-row launch); FLOPs are counted for the
+    22 880 real rows on both sides. `uv_unpadded_*`: the same call on the bare 22 880 rows (main launch + a 96-row strip launch), what
+    rounds 3-4 reported here. Calibration only - the product path never calls a vendor GEMM."""
     from univid_amd import _lib
     from univid_amd._lib import EPI_BF16
+    from univid_amd.wan.model import _ffn0_rows
     M, N, K = 22880, 14336, 3072
+    Mp = _ffn0_rows(M, N, torch.device(device))
     g = torch.Generator(device=device).manual_seed(0)
-    A = (torch.rand(M, K, device=device, generator=g) * 2 - 1).to(torch.bfloat16)
+    Ap = torch.zeros(Mp, K, device=device, dtype=torch.bfloat16)
+    Ap[:M] = (torch.rand(M, K, device=device, generator=g) * 2 - 1).to(torch.bfloat16)
+    A = Ap[:M]
     W = ((torch.rand(N, K, device=device, generator=g) * 2 - 1) * 0.05).to(torch.bfloat16)
-    out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-    res = {"hipblaslt": [], "uv_gemm_bf16_nt": []}
-    fns = {"hipblaslt": lambda: torch.nn.functional.linear(A, W), "uv_gemm_bf16_nt": lambda: _lib.gemm_bf16(A, W, None, out, EPI_BF16)}
+    out = torch.empty(Mp, N, device=device, dtype=torch.bfloat16)
+    fns = {"hipblaslt": lambda: torch.nn.functional.linear(A, W), "uv_gemm_bf16_nt": lambda: _lib.gemm_bf16(Ap, W, None, out, EPI_BF16, M=Mp),
+           "uv_unpadded": lambda: _lib.gemm_bf16(A, W, None, out, EPI_BF16, M=M)}
+    res = {k: [] for k in fns}
     for _ in range(3):
         for name, fn in fns.items():
             for _ in range(2):
@@ -71,10 +79,13 @@ def hipblaslt_ref(device):
             res[name].append(s.elapsed_time(e) / 5)
     fl = 2.0 * M * N * K
     med = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
-    return {"shape": f"{M}x{N}x{K} bf16 (ffn.0)", "hipblaslt_tflops": round(fl / med["hipblaslt"] / 1e9, 1),
+    same = bool(torch.equal(out[:M], (lambda: (_lib.gemm_bf16(A, W, None, torch.empty(M, N, device=device, dtype=torch.bfloat16), EPI_BF16, M=M)))()))
+    return {"shape": f"{M}x{N}x{K} bf16 (ffn.0)", "uv_rows_launched": Mp, "hipblaslt_tflops": round(fl / med["hipblaslt"] / 1e9, 1),
             "uv_gemm_bf16_nt_tflops": round(fl / med["uv_gemm_bf16_nt"] / 1e9, 1),
             "ratio": round(med["hipblaslt"] / med["uv_gemm_bf16_nt"], 3),
-            "note": "same run, outside the timed region, interleaved; uv time includes its leftover-row launch"}
+            "uv_unpadded_tflops": round(fl / med["uv_unpadded"] / 1e9, 1), "ratio_unpadded": round(med["hipblaslt"] / med["uv_unpadded"], 3),
+            "padded_equals_unpadded_bitwise": same,
+            "note": "same run, outside the timed region, interleaved; ratio = vendor time / this kernel's time in the product's launch form (rows padded to whole tiles, FLOPs of the real rows)"}
 
 
 def self_attn_flops(L, d):
@@ -259,19 +270,22 @@ def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=
     return res
 
 
-def stress_shape_probe(device, base_cfg, blocks=2):
-    """north_star's utilisation target is quoted at the literal 49 x 90 x 160 latent (L = 176 400 tokens), where a whole 30-block step
-    takes 22 s (profiles/r02_bench_shapeB_L176400.json: 47.3 %). This times the SAME forward (cond + uncond stacked, full TI2V-5B width)
-    on the first `blocks` of the 30 blocks - per-block work and kernels do not depend on the block count - outside the timed region of
-    the metric, so that the figure is measured in every default run. NOT the metric; labelled as a partial stack."""
+def stress_shape_probe(device, base_cfg, blocks=30, model=None):
+    """north_star's utilisation target is quoted at the literal 49 x 90 x 160 latent (L = 176 400 tokens; 13 PFLOP per forward, 26 per CFG step).
+    Round 5 (verdict item 5): the WHOLE 30-block TI2V-5B stack - the bench's own model - one warm-up forward pair (context work, kernel
+    load), then ONE timed forward pair (cond + uncond stacked, exactly the step's DiT work), outside the timed region of the metric.
+    blocks < 30 (developer runs, --stress-blocks): a partial stack built for the probe; labelled. NOT the metric."""
     from univid_amd import _lib
     cfg = dict(base_cfg, num_layers=blocks)
     latent_shape, L = (48, 49, 90, 160), 49 * 45 * 80
-    model = build_model(cfg, device, seed=0)
+    own = model is None
+    if own:
+        model = build_model(cfg, device, seed=0)
     g = torch.Generator(device=device).manual_seed(7)
     lat = torch.randn(*latent_shape, device=device, generator=g)
     ctx = [torch.randn(77, cfg["text_dim"], device=device, generator=g) * 0.1, torch.randn(12, cfg["text_dim"], device=device, generator=g) * 0.1]
     tvec = torch.full((2, L), 500.0, device=device)
+    torch.cuda.reset_peak_memory_stats(device)
     with torch.no_grad(), model.context_cached():
         model([lat, lat], t=tvec, context=ctx, seq_len=L)                     # warm-up (and the context work)
         torch.cuda.synchronize()
@@ -284,16 +298,73 @@ def stress_shape_probe(device, base_cfg, blocks=2):
     fl = 2 * dit_forward_flops(L, cfg, executed=True) - twin_saved_flops(L, cfg)
     self_ev = [(s_, e_, f) for s_, e_, f in prof["uv_flash_attn_bf16"] if f >= 2 * self_attn_flops(L, cfg["dim"]) * 0.99]
     att_ms = sum(s_.elapsed_time(e_) for s_, e_, _ in self_ev) / max(len(self_ev), 1)
-    res = {"workload": f"STRESS SHAPE, partial stack (not the metric): literal 49x90x160 latent [48,49,90,160], L={L} tokens, cond+uncond "
-                       f"stacked, TI2V-5B width, the first {blocks} of 30 blocks + embeddings + head; one forward pair timed after one warm-up",
-           "seconds": round(dt, 3), "tflop": round(fl / 1e12, 1), "tflops": round(fl / dt / 1e12, 1),
+    res = {"workload": f"STRESS SHAPE (not the metric): literal 49x90x160 latent [48,49,90,160], L={L} tokens, cond+uncond stacked, TI2V-5B width, "
+                       + (f"ALL {blocks} blocks" if blocks == base_cfg["num_layers"] else f"partial stack: the first {blocks} of {base_cfg['num_layers']} blocks")
+                       + " + embeddings + head; one forward pair timed after one warm-up pair",
+           "blocks": blocks, "seconds": round(dt, 3), "tflop": round(fl / 1e12, 1), "tflops": round(fl / dt / 1e12, 1),
            "mfma_frac": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "target": "north_star: >= 0.40 at this latent",
-           "self_attention": {"avg_launch_ms": round(att_ms, 2), "tflops": round(2 * self_attn_flops(L, cfg["dim"]) / (att_ms * 1e-3) / 1e12, 1) if att_ms else None,
+           "memory_high_water_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+           "self_attention": {"avg_launch_ms": round(att_ms, 2), "launches_timed": len(self_ev),
+                              "tflops": round(2 * self_attn_flops(L, cfg["dim"]) / (att_ms * 1e-3) / 1e12, 1) if att_ms else None,
                               "frac": round(2 * self_attn_flops(L, cfg["dim"]) / (att_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if att_ms else None},
            "finite": bool(torch.isfinite(out[0]).all().item())}
-    del model, out
+    del out
+    if own:
+        del model
     torch.cuda.empty_cache()
     return res
+
+
+def ranker_probe(device, frames=64, reps=9):
+    """BASELINE.json config 5 (reference models/BAGEL/eval_understanding.py:171-206): SigLIP2-base patch16 encode of 64 keyframes per
+    video for the Pyramid-Reflection ranker, fp16 as the reference loads it (:172), random-init weights of the siglip2-base geometry
+    (768-d, 12 layers, 12 heads x 64, 256 patches of 16x16x3; NaFlex inputs pixel_values [64, 256, 768], full masks, 16x16 grids), one
+    64-token text query: Siglip2Scorer.rank_frames = text tower + vision tower on the 64 frames + cosine top-8, replayed from the
+    vision tower's HIP graph (its default). frames/s = 64 / median wall time of `reps` calls. FLOPs per frame: 12 layers x ((8 h^2 + 4 h f)
+    per token x 256 + attention 4 L^2 h) + patch embedding + pooling head = 46.5 GFLOP. OUTSIDE the metric's timed region."""
+    from univid_amd.understanding import Siglip2Model, Siglip2Scorer
+    V = dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, num_channels=3, patch_size=16,
+             num_patches=256, layer_norm_eps=1e-6)
+    T = dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, vocab_size=32000,
+             max_position_embeddings=64, projection_size=768, layer_norm_eps=1e-6)
+    with torch.device(device):
+        m = Siglip2Model(dict(vision=V, text=T))
+    m.init_weights(0).eval()
+    B, N = frames, 256
+    g = torch.Generator(device=device).manual_seed(0)
+    pv = torch.randn(B, N, 768, device=device, generator=g)
+    mask = torch.ones(B, N, dtype=torch.int64, device=device)
+    shapes = torch.tensor([[16, 16]] * B, device=device)
+    ids = torch.randint(0, 32000, (1, 64), device=device, generator=g)
+
+    class Proc:
+        def __call__(self, images=None, text=None, return_tensors="pt"):
+            if text is not None:
+                return {"input_ids": ids}
+            i = torch.tensor(images)
+            return {"pixel_values": pv[i], "pixel_attention_mask": mask[i], "spatial_shapes": shapes[i]}
+
+    sc = Siglip2Scorer(device=device, model=m, processor=Proc())
+    h, f, L, nl = 768, 3072, 256, 12
+    flops_frame = nl * (L * (8 * h * h + 4 * h * f) + 4 * L * L * h) + 2 * L * 768 * h + (2 * L * 2 * h * h + 4 * L * h + 2 * h * h + 4 * h * f)
+    res = {}
+    for name, fn in (("rank_frames", lambda: sc.rank_frames(list(range(B)), "q", 8)), ("image_features", lambda: m.get_image_features(pv, mask, shapes))):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[len(ts) // 2]
+        res[name] = {"ms": round(t * 1e3, 3), "frames_per_sec": round(B / t, 1), "tflops": round(B * flops_frame / t / 1e12, 1),
+                     "frac_fp16_peak": round(B * flops_frame / t / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    return {"workload": f"BASELINE config 5: SigLIP2-base patch16, {B} keyframes x 256 patches, fp16, random-init; rank_frames = text query + {B} frames + cosine top-8 "
+                        "(eval_understanding.py:171-206); image_features = the vision tower alone; median of %d calls, HIP-graph replay of the tower" % reps,
+            "metric": "ranker_frames_per_sec", "value": res["rank_frames"]["frames_per_sec"], "unit": "frames/s", "dtype": "fp16",
+            "gflop_per_frame": round(flops_frame / 1e9, 1), **res,
+            "note": "launch/latency-bound at this size (2.9 TFLOP per call): the fraction of the fp16 MFMA peak is reported, not a target"}
 
 
 def build_model(cfg, device, seed=0):
@@ -476,7 +547,9 @@ def main():
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--no-pipeline-path", action="store_true", help="skip the (untimed-region) generation through CrossAttentionFusionPipeline, UniVid's own entry point")
     ap.add_argument("--no-default-shape", action="store_true", help="skip the (untimed-region) 3-step run at UniVid's default 121-frame latent (L = 27 280)")
-    ap.add_argument("--no-stress-shape", action="store_true", help="skip the (untimed-region) 2-block probe at the literal 49x90x160 latent")
+    ap.add_argument("--no-stress-shape", action="store_true", help="skip the (untimed-region) full-stack forward pair at the literal 49x90x160 latent (~35 s)")
+    ap.add_argument("--stress-blocks", type=int, default=0, help="developer runs: the stress-shape probe on a partial stack of this many blocks")
+    ap.add_argument("--no-ranker", action="store_true", help="skip the (untimed-region) SigLIP2 ranker measurement (BASELINE config 5)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer DiT blocks (result is NOT the metric)")
     ap.add_argument("--kernel-times", action="store_true", help="HIP-event timing of every kernel class (adds ~1%% overhead)")
     ap.add_argument("--shape", choices=["A", "B"], default="A", help="A (default, the metric): 49-frame 704x1280 latent [48,13,44,80], "
@@ -685,13 +758,20 @@ def main():
             except Exception as ex:      # a side measurement: never fails the bench
                 out["default_shape"] = {"error": repr(ex)[:300]}
         if world == 1 and not args.no_stress_shape and not args.layers and args.shape == "A":
-            del model                                            # the 30 GB of DiT weights are not needed any more
-            model = None
+            runner = None
             torch.cuda.empty_cache()
             try:
-                out["stress_shape"] = stress_shape_probe(device, dict(TI2V_5B_CFG))
+                if args.stress_blocks and args.stress_blocks != cfg["num_layers"]:
+                    out["stress_shape"] = stress_shape_probe(device, dict(TI2V_5B_CFG), blocks=args.stress_blocks)
+                else:
+                    out["stress_shape"] = stress_shape_probe(device, dict(TI2V_5B_CFG), blocks=cfg["num_layers"], model=model)
             except Exception as ex:      # a side measurement: never fails the bench
                 out["stress_shape"] = {"error": repr(ex)[:300]}
+        if world == 1 and not args.no_ranker and args.shape == "A":
+            try:
+                out["ranker"] = ranker_probe(device)
+            except Exception as ex:      # a side measurement: never fails the bench
+                out["ranker"] = {"error": repr(ex)[:300]}
         if world == 1 and not args.no_vae and not args.layers and args.shape == "A":
             model = None                                         # the 30 GB of DiT weights are not needed any more
             torch.cuda.empty_cache()
