@@ -253,7 +253,9 @@ def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=
         lat_n, res["native"] = timed(fusion, steps)
         res["native"]["graph"] = pipe._runner is not None
         res["native"]["note"] = ("whole generation incl. ContextProjector, graph-buffer refreshes of the weighted steps, sampler set-up; "
-                                 "text weight as data on the fast path (WanModel.set_text_weight / _GraphedPair.apply)")
+                                 "text weight as data on the fast path (WanModel.set_text_weight / _GraphedPair.apply). host_cpu_ms_per_step here is process CPU "
+                                 "time over the WHOLE call, i.e. including the time the host waits for the GPU (the loop keeps <= 4 steps queued and naps; what "
+                                 "remains is a ROCm runtime thread that polls while work is pending) - the headline's figure is the enqueue time only")
         # same first steps through both mechanisms: bit-identical latents (also tests/test_pipeline_path.py)
         lat_a, _ = fusion.generate_video_with_bagel_context("a prompt", steps=closure_steps, **kw)
         lat_a = lat_a.clone()

@@ -10,10 +10,12 @@ i2v :413-619) with the same method names, keyword arguments and defaults. Differ
     (288 GB HBM: nothing is ever moved to the host).
   * generation errors raise instead of being swallowed.
 """
+import collections
 import contextlib
 import math
 import random
 import sys
+import time
 from typing import Callable, List, Optional
 
 import torch
@@ -254,6 +256,8 @@ class WanTI2V:
         self.sp_size = 1
         self.cfgp = None
         self._runner = None      # cached _GraphedPair (HIP graph of the CFG pair's forward) of the last graph-mode denoise
+        self._progress, self._steps_issued = None, 0
+        self.max_steps_in_flight = 4       # sampler steps the host may queue ahead of the GPU (WanTI2V._steps)
         self.text_weight_schedule = None   # object with next_pair() / rows(text_len) / layers: UniVid's dynamic text weight, native
         self.sample_neg_prompt = config.sample_neg_prompt
         self.text_encoder = text_encoder
@@ -388,7 +392,15 @@ class WanTI2V:
     def _steps(self, sched, timesteps, latent, context, context_null, guide_scale, z, mask2, base_mask, seq_len, record, runner, tws):
         dev = self.device
         i2v = z is not None
+        # The host runs ahead of the GPU (nothing in a step synchronises). Unbounded, it runs into the HIP runtime's launch queue: from about
+        # the 23rd queued graph replay on, the launch call blocks by SPINNING (measured at L = 11 440: a 50-step generation burned 13.7 s of
+        # CPU time on two threads for 12.6 s of GPU work, while 20 steps cost 9 ms) - one or two busy cores per rank, for nothing. So the loop
+        # keeps at most `max_steps_in_flight` steps queued: the GPU bumps a counter in pinned host memory at the end of every step (one scalar
+        # fill + one 8-byte asynchronous copy) and the host, when it is that far ahead, naps in 1-ms slices reading that counter as plain
+        # memory - no HIP call in the wait (hipEventSynchronize, blocking flag or not, and a hipEventQuery poll both kept a core busy:
+        # measured). The GPU never starves: the queue still holds the other steps' work.
         for t in timesteps:
+            self._throttle()
             tw = None
             if tws is not None:
                 # UniVid's dynamic text weight, native (model_pipeline.py:1699-1810, 1844-1886): the wrapper's counter advances once per
@@ -408,6 +420,7 @@ class WanTI2V:
                     latent = ((1.0 - mask2[0]) * z + mask2[0] * latent).contiguous()
                 if record is not None:
                     record.append((npred, latent.clone()))
+                self._step_done()
                 continue
             ts = torch.stack([t]).to(dev)
             temp_ts = base_mask * ts                                                   # :373
@@ -444,7 +457,24 @@ class WanTI2V:
                 latent = ((1.0 - mask2[0]) * z + mask2[0] * latent).contiguous()       # :598
             if record is not None:
                 record.append((npred, latent.clone()))
+            self._step_done()
         return latent
+
+    # ---- host pacing: a step counter the GPU writes into pinned host memory at the end of every step; the host reads it as plain memory
+    def _step_done(self):
+        if self._progress is None:
+            self._progress = (torch.zeros(1, dtype=torch.int64, device=self.device), torch.zeros(1, dtype=torch.int64).pin_memory())
+        self._steps_issued += 1
+        dev_ctr, host_ctr = self._progress
+        dev_ctr.fill_(self._steps_issued)
+        host_ctr.copy_(dev_ctr, non_blocking=True)
+
+    def _throttle(self):
+        if self._progress is None:
+            return
+        host_ctr = self._progress[1]
+        while self._steps_issued - int(host_ctr[0]) >= self.max_steps_in_flight:
+            time.sleep(1e-3)
 
     def _noise(self, shape, seed):
         seed = seed if seed >= 0 else random.randint(0, sys.maxsize)
