@@ -2707,11 +2707,23 @@ def _cfgp_gpu_worker(rank, world, port, q, nccl=False):
         with torch.no_grad():
             plain = pipe.denoise(*args)
             plain_i2v = pipe.denoise(*args, z=g["z"].to(DEV))
+            # UniVid's dynamic text weight (native schedule): the single-process loop gives the CFG pair the counter's two consecutive
+            # values; under CFG parallelism each rank runs ONE of the two forwards and must take that forward's value
+            import logging
+            from univid_amd.model_pipeline import CrossAttentionConfig, Wan22ContextWrapper
+            wr = Wan22ContextWrapper(pipe, None, logging.getLogger("t"), CrossAttentionConfig(use_dynamic_text_weight=True, total_sampling_steps=8,
+                                                                                             text_weight_transition_ratio=0.75, text_weight_schedule="linear"))
+            wr.set_bagel_context(torch.zeros(1, 2, 2))
+            with wr.scheduled():
+                weighted = pipe.denoise(*args)
             pipe.enable_cfg_parallel()
             rec = []
             split = pipe.denoise(*args, record=rec)
             split_i2v = pipe.denoise(*args, z=g["z"].to(DEV))
+            with wr.scheduled():
+                split_weighted = pipe.denoise(*args)
         ok = torch.equal(split, plain) and torch.equal(split_i2v, plain_i2v) and len(rec) == 4
+        ok = ok and torch.equal(split_weighted, weighted) and not torch.equal(weighted, plain)
         q.put((rank, bool(ok), pipe.cfgp.branch, float((split - plain).abs().max())))
     finally:
         dist.destroy_process_group()
@@ -2752,7 +2764,19 @@ def _replica_gpu_worker(rank, world, port, q, nccl=False):
         with torch.no_grad():
             alone = [pipe.denoise(noises[i], ctxs[i], nulls[i], 3, g["shift"], g["guide_scale"]) for i in range(n)]
             got = parallel.denoise_batch(pipe, noises, ctxs, nulls, 3, g["shift"], g["guide_scale"])
+            # the pipeline path (round 5): every sample one generation under this rank's Wan22ContextWrapper (forward counter per sample)
+            import logging
+            from univid_amd.model_pipeline import CrossAttentionConfig, Wan22ContextWrapper
+            wr = Wan22ContextWrapper(pipe, None, logging.getLogger("t"), CrossAttentionConfig(use_dynamic_text_weight=True, total_sampling_steps=6,
+                                                                                             text_weight_transition_ratio=0.7))
+            wr.set_bagel_context(torch.zeros(1, 2, 2))
+            alone_w = []
+            for i in range(n):
+                with wr.scheduled():
+                    alone_w.append(pipe.denoise(noises[i], ctxs[i], nulls[i], 3, g["shift"], g["guide_scale"]).clone())
+            got_w = parallel.denoise_batch(pipe, noises, ctxs, nulls, 3, g["shift"], g["guide_scale"], wrapper=wr)
         ok = len(got) == n and all(torch.equal(a, b) for a, b in zip(got, alone))
+        ok = ok and len(got_w) == n and all(torch.equal(a, b) for a, b in zip(got_w, alone_w)) and not torch.equal(alone_w[0], alone[0])
         q.put((rank, bool(ok), str(got[0].device)))
     finally:
         dist.destroy_process_group()
@@ -2862,6 +2886,27 @@ def test_full_size_t2v_and_i2v_end_to_end():
     assert v1.shape == (3, 49, 704, 1280) and torch.isfinite(v1).all() and v1.abs().max() <= 1.0
     assert lat2.shape == (48, 13, 44, 80) and torch.equal(lat2, lat3)
     assert li.shape == (48, 13, 44, 80) and torch.isfinite(li).all()
+    # the same clip through UniVid's own entry point (inference.py:311,377 -> model_pipeline.py:2577-2655) at full size: with the weight
+    # schedule flat (max = min = 1) it IS the plain path - video and i2v latent bit for bit -; with inference.py's schedule it runs on the
+    # same graph replay (no re-assigned forwards anywhere), differs, and stays finite
+    import types
+    from univid_amd.model_pipeline import CrossAttentionConfig, CrossAttentionFusionPipeline
+    bagel = types.SimpleNamespace(extract_semantic_tokens=lambda text, image: torch.zeros(1, 128, 3584, device=DEV, dtype=BF16))
+    kw = dict(steps=2, guidance_scale=5.0, frames=49, size=(1280, 704), shift=5.0, prompt_embeds=pe, negative_prompt_embeds=ne)
+    flat = CrossAttentionFusionPipeline(CrossAttentionConfig(use_lora=False, text_weight_max=1.0, text_weight_min=1.0, total_sampling_steps=2),
+                                        wan_pipeline=pipe, bagel_extractor=bagel)
+    sched = CrossAttentionFusionPipeline(CrossAttentionConfig(use_lora=False, total_sampling_steps=10), wan_pipeline=pipe, bagel_extractor=bagel)
+    with torch.no_grad():
+        pv, path = flat.generate_video_with_bagel_context("", seed=7, **kw)
+        assert path is None and torch.equal(pv, v1)
+        del pv
+        pli, _ = flat.generate_video_with_bagel_context("", image=img, seed=3, decode=False, **kw)
+        assert torch.equal(pli, li)
+        runner = pipe._runner
+        wl, _ = sched.generate_video_with_bagel_context("", seed=7, decode=False, **kw)
+    assert pipe._runner is not None and all("forward" not in b.cross_attn.__dict__ for b in m.blocks) and "forward" not in m.__dict__
+    assert torch.isfinite(wl).all() and not torch.equal(wl, lat2)
+    assert any(s != (1.0, 1.0) for s in pipe._runner.state), "2 of 10 scheduled steps ran: the runner's K / V^T must still hold weighted context"
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -48,5 +48,22 @@ for F in frames:
         print(f"{F:3d} frames, VAE {prec:7s}: t2v {steps} steps {t_den:6.2f} s ({t_den / steps * 1e3:.1f} ms/step) + decode {t_dec:5.2f} s = "
               f"{t_den + t_dec:6.2f} s per {F}-frame 704x1280 clip (latent {list(lat.shape)}); i2v (encode 1 frame + {steps} steps + decode) "
               f"{t_i2v:6.2f} s; finite {bool(torch.isfinite(vid).all())}", flush=True)
+        if prec == "f16x3":
+            # the same clip through UniVid's OWN entry point (inference.py:311,377 -> CrossAttentionFusionPipeline.generate_video_with_bagel_context,
+            # models/model_pipeline.py:2577-2655) with inference.py's dynamic text weight (cosine 1.3 -> 1.0 over the first 40 % of the steps):
+            # the native schedule keeps it on the graph-replay path, so it must cost what the plain t2v + decode above cost
+            import types
+            from univid_amd.model_pipeline import CrossAttentionConfig, CrossAttentionFusionPipeline
+            bagel = types.SimpleNamespace(extract_semantic_tokens=lambda text, image: torch.zeros(1, 128, 3584, device=dev, dtype=torch.bfloat16))
+            ccfg = CrossAttentionConfig(use_lora=False, use_dynamic_text_weight=True, total_sampling_steps=steps)
+            fusion = CrossAttentionFusionPipeline(ccfg, wan_pipeline=pipe, bagel_extractor=bagel, context_projector=None)
+            kw = dict(steps=steps, guidance_scale=5.0, frames=F, size=(1280, 704), shift=5.0, seed=7, prompt_embeds=pe, negative_prompt_embeds=ne)
+            with torch.no_grad():
+                (v2, _), t_pipe = clock(lambda: fusion.generate_video_with_bagel_context("", **kw))
+                (_, _), t_pipe_i2v = clock(lambda: fusion.generate_video_with_bagel_context("", image=img, **dict(kw, seed=3)))
+            print(f"{F:3d} frames, VAE {prec:7s}: through CrossAttentionFusionPipeline (dynamic text weight, native schedule): t2v + decode {t_pipe:6.2f} s, "
+                  f"i2v {t_pipe_i2v:6.2f} s; finite {bool(torch.isfinite(v2).all())}", flush=True)
+            fusion.cleanup_resources()
+            del fusion, v2
         del vae, pipe, vid, lat
         torch.cuda.empty_cache()

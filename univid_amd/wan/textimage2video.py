@@ -463,7 +463,8 @@ class WanTI2V:
     # ---- host pacing: a step counter the GPU writes into pinned host memory at the end of every step; the host reads it as plain memory
     def _step_done(self):
         if self._progress is None:
-            self._progress = (torch.zeros(1, dtype=torch.int64, device=self.device), torch.zeros(1, dtype=torch.int64).pin_memory())
+            with torch.inference_mode(False):      # normal tensors: written in place by later calls inside or outside inference mode
+                self._progress = (torch.zeros(1, dtype=torch.int64, device=self.device), torch.zeros(1, dtype=torch.int64).pin_memory())
         self._steps_issued += 1
         dev_ctr, host_ctr = self._progress
         dev_ctr.fill_(self._steps_issued)
