@@ -50,6 +50,7 @@ int uv_reset_options(void);
 #define UV_EPI_RESID_F32 3       /* x_f32   += float(bf16(acc + bias))                        x + cross_attn(...), model.py:251 */
 #define UV_EPI_GATE_RESID_F32 4  /* x_f32    = x + float(bf16(acc + bias)) * gate[tid[m]][n]  x + y*e, model.py:247,255 */
 #define UV_EPI_BF16_T 5          /* outT_bf16[n][m] = bf16(acc + bias)                        V^T for uv_flash_attn_bf16 */
+/* (6 = UV_EPI_BF16 + per-group sums of squares: reached through uv_gemm_bf16_nt_ssq, which carries the extra output) */
 
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, bf16 operands, fp32 accumulate (MFMA 16x16x32).
  * Replaces nn.Linear q/k/v/o, ffn.0/ffn.2, text_embedding, patch_embedding (model.py:119-122, 212-214, 378-382).
@@ -63,6 +64,18 @@ int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw, const void
  * ranker in (models/BAGEL/eval_understanding.py:172,181,191: fp16 autocast). Same epilogues; tile_cfg must be 0. */
 int uv_gemm_f16_nt(const void* A, long lda, const void* W, long ldw, const void* bias_f16, int M, int N, int K, int epilogue,
                    void* out, long ldo, const float* gate, const int32_t* gate_tid, long gate_stride, int tile_cfg, void* stream);
+
+/* The q projection whose RMSNorm the attention kernel applies itself (WanSelfAttention / WanCrossAttention: q = norm_q(self.q(x)),
+ * model.py:138, 169; WanRMSNorm over ALL heads' columns, :82-85): out = bf16(A W^T + bias) exactly as UV_EPI_BF16, and in the same pass
+ * ssq[m][g] = sum over the 32 columns n in [32 g, 32 g + 32) of float(out[m][n])^2, f32 [M, ld_ssq], N % 32 == 0, ld_ssq >= N / 32.
+ * Every group is summed in ONE fixed order whatever kernel and tile shape computes it (quads of 4 consecutive columns left to right, then
+ * (s_k + s_{k+4}) pairs, then a balanced tree), so the values do not depend on the schedule. uv_rms_scale_from_ssq turns them into the
+ * per-row scale uv_flash_attn_bf16_qnorm consumes: one pass over q (read + write of [M, N] bf16) is gone. */
+int uv_gemm_bf16_nt_ssq(const void* A, long lda, const void* W, long ldw, const void* bias_bf16, int M, int N, int K, void* out, long ldo,
+                        float* ssq, long ld_ssq, int tile_cfg, void* stream);
+/* rs[m] = 1 / sqrt(sum_g ssq[m][g] / C + eps), groups added in a fixed order (four ascending quarter sums, then (p0 + p1) + (p2 + p3)):
+ * WanRMSNorm's x.pow(2).mean(-1) + eps, rsqrt (model.py:85). */
+int uv_rms_scale_from_ssq(const float* ssq, long ld_ssq, int M, int groups, int C, float eps, float* rs, void* stream);
 
 /* C[M,N] = A[M,K] . W[N,K]^T + bias (+ resid), all fp32, exact-f32 MFMA (16x16x4).
  * Replaces Head.head (fp32 island, model.py:286-290) and the VAE's 1x1 convolutions (vae2_2.py:211,249-250,766-767).
@@ -79,6 +92,13 @@ int uv_gemm_f32_nt(const float* A, long lda, const float* W, long ldw, const flo
  * that bound finite, Lk % 8 == 0 when batch > 1; out [batch*Lq, ldo]; head_dim D in {64, 128}. */
 int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                        int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream);
+
+/* uv_flash_attn_bf16 on the RAW q projection: the Q prologue of every kernel applies norm_q - q'[m][c] = bf16( bf16(q[m][c] * q_rs[m]) * q_weight[c] ),
+ * the roundings of uv_rmsnorm_rope - before the first MFMA. q_rs f32 [batch * Lq] (uv_rms_scale_from_ssq), q_weight f32 [H * D] (norm_q.weight).
+ * No rotary embedding: the cross-attention form (model.py:160-180). k / vt as for uv_flash_attn_bf16 (k already normalised). */
+int uv_flash_attn_bf16_qnorm(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                             int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, const float* q_rs, const float* q_weight,
+                             void* stream);
 
 /* uv_flash_attn_bf16 with IEEE fp16 q / k / vt / out (SigLIP2 ranker: transformers' attention under fp16 autocast). */
 int uv_flash_attn_f16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,

@@ -442,10 +442,11 @@ def test_context_cache_is_scoped_and_survives_inference_tensors():
 
 def test_vae_pass_length_falls_back_when_memory_runs_out():
     """WanVAE_._with_pass_length: an out-of-memory error at `frames_per_pass` frames retries with half the pass length down to the
-    reference's 1 (the result does not depend on it); at 1 the error propagates."""
+    reference's 1 (the result does not depend on it), with the engine and its workspace arena released first; at 1 the error propagates."""
     import types
     m = WanVAE_(dim=32, dec_dim=32, z_dim=48, dim_mult=(1, 2, 4, 4), temperal_downsample=(False, True, True))
     m._engine = types.SimpleNamespace(scratch={"k": 1})
+    m._pool = object()
     m.frames_per_pass = 8
     seen = []
 
@@ -455,7 +456,8 @@ def test_vae_pass_length_falls_back_when_memory_runs_out():
             raise torch.cuda.OutOfMemoryError("simulated")
         return (tag, G)
 
-    assert m._with_pass_length(body, "x") == ("x", 2) and seen == [8, 4, 2] and m._engine.scratch == {}
+    # (round 5: the engine's cached frames and rings live in the VAE's workspace arena: both are dropped before the retry)
+    assert m._with_pass_length(body, "x") == ("x", 2) and seen == [8, 4, 2] and m._engine is None and m._pool is None
 
     def always(G):
         raise torch.cuda.OutOfMemoryError("simulated")

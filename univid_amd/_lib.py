@@ -28,6 +28,9 @@ SIGNATURES = {
     "uv_gemm_bf16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
     "uv_gemm_f16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
     "uv_gemm_f32_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _P],
+    "uv_gemm_bf16_nt_ssq": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _I, _P],
+    "uv_rms_scale_from_ssq": [_P, _L, _I, _I, _I, _F, _P, _P],
+    "uv_flash_attn_bf16_qnorm": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _P, _P],
     "uv_flash_attn_bf16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "uv_flash_attn_f16": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P],
     "uv_flash_attn_kernel_name": [_I, _I, _L, _L, _I, _c.c_char_p, _I],
@@ -254,6 +257,26 @@ def gemm_bf16(a, w, bias, out, epi, M=None, gate=None, gate_tid=None, tile_cfg=0
     return out
 
 
+def gemm_bf16_ssq(a, w, bias, out, ssq, M=None, tile_cfg=0):
+    """out = bf16(a w^T + bias) and ssq[m][g] = the output row's sum of squares over columns [32 g, 32 g + 32) (f32 [M, N / 32])."""
+    _chk(a, torch.bfloat16, "gemm_bf16_ssq.a")
+    _chk(w, torch.bfloat16, "gemm_bf16_ssq.w")
+    _chk(ssq, torch.float32, "gemm_bf16_ssq.ssq")
+    M = a.shape[0] if M is None else M
+    N, K = w.shape
+    call("uv_gemm_bf16_nt_ssq", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), M, N, K, ptr(out), out.stride(0), ptr(ssq), ssq.stride(0),
+         tile_cfg, stream_ptr(), flops=2 * M * N * K)
+    return out
+
+
+def rms_scale_from_ssq(ssq, rs, M, C, eps):
+    """rs[m] = 1 / sqrt(sum(ssq[m]) / C + eps): the RMSNorm scale of row m from its per-group sums of squares."""
+    _chk(ssq, torch.float32, "rms_scale_from_ssq.ssq")
+    _chk(rs, torch.float32, "rms_scale_from_ssq.rs")
+    call("uv_rms_scale_from_ssq", ptr(ssq), ssq.stride(0), M, ssq.shape[1], C, float(eps), ptr(rs), stream_ptr())
+    return rs
+
+
 def gemm_f32(a, w, bias, out, resid=None, M=None):
     _chk(a, torch.float32, "gemm_f32.a")
     _chk(w, torch.float32, "gemm_f32.w")
@@ -264,11 +287,18 @@ def gemm_f32(a, w, bias, out, resid=None, M=None):
     return out
 
 
-def flash_attn(q, k, vt, out, Lq, Lk, H, D, scale, batch=1):
-    """q [batch*Lq, C], k [batch*Lk, C], vt [C, >= (batch-1)*Lk + roundup(Lk, 64)] (sample b = columns b*Lk..), out [batch*Lq, C]."""
+def flash_attn(q, k, vt, out, Lq, Lk, H, D, scale, batch=1, q_rs=None, q_weight=None):
+    """q [batch*Lq, C], k [batch*Lk, C], vt [C, >= (batch-1)*Lk + roundup(Lk, 64)] (sample b = columns b*Lk..), out [batch*Lq, C].
+    q_rs / q_weight: q is the RAW projection and the kernel's Q prologue applies norm_q (per-row scale f32 [batch*Lq], weight f32 [C])."""
     f16 = q.dtype == torch.float16
     for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (out, "out")):
         _chk(t, q.dtype if f16 else torch.bfloat16, "flash_attn." + n)
+    if q_rs is not None:
+        _chk(q_rs, torch.float32, "flash_attn.q_rs")
+        _chk(q_weight, torch.float32, "flash_attn.q_weight")
+        call("uv_flash_attn_bf16_qnorm", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(vt), vt.stride(0), ptr(out), out.stride(0),
+             batch, Lq, Lk, H, D, float(scale), ptr(q_rs), ptr(q_weight), stream_ptr(), flops=4 * batch * Lq * Lk * H * D)
+        return out
     call("uv_flash_attn_f16" if f16 else "uv_flash_attn_bf16", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(vt), vt.stride(0), ptr(out), out.stride(0),
          batch, Lq, Lk, H, D, float(scale), stream_ptr(), flops=4 * batch * Lq * Lk * H * D)
     return out

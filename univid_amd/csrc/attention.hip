@@ -54,8 +54,9 @@ typedef __attribute__((address_space(3))) void lds_void_a;
 // 4 waves x 32 queries per workgroup, 2 workgroups per CU: the two waves that share a SIMD then belong to DIFFERENT workgroups, are
 // not re-aligned by a common barrier every tile, and drift into complementary phases - one in its MFMA cluster while the other
 // does softmax VALU work.
-template <int D, bool SGB = false, bool F16 = false>
+template <int D, bool SGB = false, bool F16 = false, int QN = 0>
 __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs p) {
+    static_assert(!F16 || QN == 0, "the fused q-norm prologue is built for bf16 only");
     constexpr int NW = 4;
     constexpr int NT = NW * 64;
     constexpr int KROW = 2 * D;                 // bytes per K row in LDS (256 or 128)
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs p) {
     {   // independent samples are stacked along the token axis: rows of q/k/out, COLUMNS of V^T
         const long b = bh / p.H;
         p.q += b * p.Lq * p.ldq;
+        if (QN) p.q_rs += b * p.Lq;
         p.k += b * p.Lk * p.ldk;
         p.vt += (long)b * p.Lk;
         p.out += b * p.Lq * p.ldo;
@@ -88,12 +90,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs p) {
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane (r,h) holds Q[q0w+r][16kk+8h .. +7]
     bf16x8 qf[NKK];
-    {
-        const int qrow = min(q0w + r, p.Lq - 1);
-        const bf16_t* qp = p.q + (long)qrow * p.ldq + hcol + 8 * h;
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
-    }
+    AttnQNorm<NKK, QN> qnorm;
+    attn_load_q<NKK, QN>(p, qf, qnorm, min(q0w + r, p.Lq - 1), hcol, h);
 
     // ---- staging: K and V^T tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction,
     // no VGPR round trip and no ds_write: the VGPR->LDS store path measured 440-700 cycles per tile when all waves of
@@ -183,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs p) {
     const int nt = (p.Lk + UV_ATT_KV - 1) / UV_ATT_KV;
     const int nt_full = p.Lk / UV_ATT_KV;
     fetch(0, 0);
+    attn_apply_qnorm<NKK, QN>(qf, qnorm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // Pin "every prologue load has landed" BEFORE the loop: vmcnt retires in order, so if the compiler has to assume
     // the Q fragment loads may still be in flight at the loop header it guards their first use inside the loop with
@@ -369,7 +368,7 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
 }
 
 // AHEAD = fragment reads in flight ahead of their MFMA (2 .. 5 measured: all within 0.5 %); XCD = XCD-aware block order (A/B knob).
-template <int AHEAD = 3, bool XCD = true>
+template <int AHEAD = 3, bool XCD = true, int QN = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void flash_attn_fwd3_kernel(AttnArgs p) {
     constexpr int D = 128, NW = 4, KROW = 256, NKK = 8, ND = 4;
     constexpr int K_BYTES = UV_ATT_KV * KROW, V_BYTES = D * 128;
@@ -398,6 +397,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     {
         const long b = bh / p.H;
         p.q += b * p.Lq * p.ldq;
+        if (QN) p.q_rs += b * p.Lq;
         p.k += b * p.Lk * p.ldk;
         p.vt += (long)b * p.Lk;
         p.out += b * p.Lq * p.ldo;
@@ -408,12 +408,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     UV_TL_HW(vb);
 
     bf16x8 qf[NKK];
-    {
-        const int qrow = min(q0w + r, p.Lq - 1);
-        const bf16_t* qp = p.q + (long)qrow * p.ldq + hcol + 8 * h;
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
-    }
+    AttnQNorm<NKK, QN> qnorm;
+    attn_load_q<NKK, QN>(p, qf, qnorm, min(q0w + r, p.Lq - 1), hcol, h);
 
     // LDS-DMA pieces of this wave: 4 of K (4 rows of 256 B each), 4 of V^T (8 rows of 128 B each); see the default kernel for
     // the row permutation and the swizzles. Piece i of a wave covers LDS rows 16 i further on (K) / 32 i (V^T); neither the
@@ -479,6 +475,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int nt_full = p.Lk / UV_ATT_KV;
     if (nt_full > 0) fetch_k_full(kbase, 0);
     else fetch_k_clamped(0, 0);
+    attn_apply_qnorm<NKK, QN>(qf, qnorm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]), "+v"(kaddr[kk]));
@@ -675,7 +672,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // take every barrier; the waves beyond the block's unit count are LOADER-ONLY (no QK / softmax / PV). Per-query arithmetic does
 // not depend on the cut: results are bit-identical for any cut.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int AHEAD = 3, bool XCD = true>
+template <int AHEAD = 3, bool XCD = true, int QN = 0>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void flash_attn_fwd12_kernel(AttnArgs p) {
     constexpr int D = 128, NW = 12, KROW = 256, NKK = 8, ND = 4;
     constexpr int K_BYTES = UV_ATT_KV * KROW, V_BYTES = D * 128;
@@ -713,6 +710,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     {
         const long b = bh / p.H;
         p.q += b * p.Lq * p.ldq;
+        if (QN) p.q_rs += b * p.Lq;
         p.k += b * p.Lk * p.ldk;
         p.vt += (long)b * p.Lk;
         p.out += b * p.Lq * p.ldo;
@@ -725,12 +723,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     UV_TL_HW(blockIdx.x);
 
     bf16x8 qf[NKK];
-    {
-        const int qrow = min(q0w + r, p.Lq - 1);
-        const bf16_t* qp = p.q + (long)qrow * p.ldq + hcol + 8 * h;
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
-    }
+    AttnQNorm<NKK, QN> qnorm;
+    attn_load_q<NKK, QN>(p, qf, qnorm, min(q0w + r, p.Lq - 1), hcol, h);
 
     // The 32 pieces of a tile (K pieces 0..15 = 4 LDS rows each, V^T pieces 0..15 = 8 rows each) are dealt round-robin: wave w
     // issues K piece w, K piece w + 12 (w < 4), V^T piece w - 4 (w >= 4) and V^T piece w + 8 (w < 8). Pieces 12 apart (K) / of equal
@@ -801,6 +795,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int nt_full = p.Lk / UV_ATT_KV;
     if (nt_full > 0) fetch_full(kbase, vbase, 0);
     else fetch_clamped(0, vbase, 0);
+    attn_apply_qnorm<NKK, QN>(qf, qnorm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(qf[kk]), "+v"(kaddr[kk]));
@@ -1074,7 +1069,8 @@ extern "C" int uv_flash_attn_kernel_name(int Lk, int head_dim, long ldk, long ld
 
 template <bool F16>
 static int attn_entry(const char* name, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
-                      int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream) {
+                      int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream, const float* q_rs = nullptr,
+                      const float* q_w = nullptr) {
     UV_CHECK_ARG(q && k && vt && out, "%s: null pointer", name);
     UV_CHECK_ARG(head_dim == 128 || head_dim == 64, "%s: head_dim %d unsupported (64 or 128)", name, head_dim);
     UV_CHECK_ARG(Lq > 0 && Lk > 0 && H > 0 && batch > 0, "%s: bad shape B=%d Lq=%d Lk=%d H=%d", name, batch, Lq, Lk, H);
@@ -1088,6 +1084,9 @@ static int attn_entry(const char* name, const void* q, long ldq, const void* k, 
     a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
     a.Lq = Lq; a.Lk = Lk; a.H = H; a.batch = batch; a.n12 = 0;
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
+    a.q_rs = q_rs; a.q_w = q_w;
+    const bool qn = q_rs != nullptr;
+    UV_CHECK_ARG(!qn || (q_w && !F16 && (((uintptr_t)q_w | (uintptr_t)q_rs) & 15) == 0), "%s: q_rs needs q_weight (f32, 16-byte aligned), bf16 only", name);
     hipStream_t st = (hipStream_t)stream;
     switch (attn_select(Lk, head_dim, ldk, ldvt, F16)) {
         case ATT_FWD12:
@@ -1102,18 +1101,26 @@ static int attn_entry(const char* name, const void* q, long ldq, const void* k, 
                 a.n12 = n12;
                 a.q_blocks = n12 + n8;
             }
-            hipLaunchKernelGGL((flash_attn_fwd12_kernel<3, true>), dim3(a.q_blocks * H * batch), dim3(768), 0, st, a);
+            if (qn) hipLaunchKernelGGL((flash_attn_fwd12_kernel<3, true, 1>), dim3(a.q_blocks * H * batch), dim3(768), 0, st, a);
+            else hipLaunchKernelGGL((flash_attn_fwd12_kernel<3, true>), dim3(a.q_blocks * H * batch), dim3(768), 0, st, a);
             break;
         case ATT_FWD3:
             a.q_blocks = (Lq + 127) / 128;
-            hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, true>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a);
+            if (qn) hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, true, 1>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((flash_attn_fwd3_kernel<3, true>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a);
             break;
         case ATT_FWD_D128:
             a.q_blocks = (Lq + 127) / 128;
+            if constexpr (!F16) {
+                if (qn) { hipLaunchKernelGGL((flash_attn_fwd_kernel<128, true, false, 1>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a); break; }
+            }
             hipLaunchKernelGGL((flash_attn_fwd_kernel<128, true, F16>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a);
             break;
         case ATT_FWD_D64:
             a.q_blocks = (Lq + 127) / 128;
+            if constexpr (!F16) {
+                if (qn) { hipLaunchKernelGGL((flash_attn_fwd_kernel<64, false, false, 1>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a); break; }
+            }
             hipLaunchKernelGGL((flash_attn_fwd_kernel<64, false, F16>), dim3(a.q_blocks * H * batch), dim3(256), 0, st, a);
             break;
     }
@@ -1124,6 +1131,16 @@ static int attn_entry(const char* name, const void* q, long ldq, const void* k, 
 extern "C" int uv_flash_attn_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                                   int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, void* stream) {
     return attn_entry<false>("uv_flash_attn_bf16", q, ldq, k, ldk, vt, ldvt, out, ldo, batch, Lq, Lk, H, head_dim, softmax_scale, stream);
+}
+
+// uv_flash_attn_bf16 on a RAW q projection: WanRMSNorm of q (norm_q, model.py:138 / 169) applied in the kernels' Q prologue from the per-row scale
+// q_rs (uv_rms_scale_from_ssq of the q GEMM's sums of squares) and the norm weight - the separate pass over q is gone. No RoPE here (cross-attention).
+extern "C" int uv_flash_attn_bf16_qnorm(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                                        int batch, int Lq, int Lk, int H, int head_dim, float softmax_scale, const float* q_rs,
+                                        const float* q_weight, void* stream) {
+    UV_CHECK_ARG(q_rs && q_weight, "uv_flash_attn_bf16_qnorm: q_rs / q_weight missing");
+    return attn_entry<false>("uv_flash_attn_bf16_qnorm", q, ldq, k, ldk, vt, ldvt, out, ldo, batch, Lq, Lk, H, head_dim, softmax_scale, stream,
+                             q_rs, q_weight);
 }
 
 // The same with IEEE fp16 q / k / V^T / out (fp32 softmax and accumulation): the SigLIP2 ranker's reference dtype.

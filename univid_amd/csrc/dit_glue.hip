@@ -620,6 +620,42 @@ extern "C" int uv_text_weight_rows_bf16(const void* in, long ldi, void* out, lon
 }
 
 // ------------------------------------------------------------------------------------------------
+// WanRMSNorm's per-row scale from the sums of squares a q projection's GEMM epilogue left per 32-column group (uv_gemm_bf16_nt_ssq):
+// rs[m] = 1 / sqrt(sum_g ssq[m][g] / C + eps) (f32; the formula of rmsnorm_rope_kernel: mean = sum / C; 1.0f / sqrtf(mean + eps)), the groups
+// added in a fixed order. Consumed by uv_flash_attn_bf16_qnorm's Q prologue.
+// ------------------------------------------------------------------------------------------------
+// Four lanes per row: lane part p adds its quarter of the row's groups in ascending order (16-byte loads where the quarter allows), the four
+// quarter sums are combined as (p0 + p1) + (p2 + p3). 64 rows per 256-thread block, a row's loads contiguous across its four lanes.
+__global__ __launch_bounds__(256) void rms_scale_from_ssq_kernel(const float* ssq, long ld, int M, int groups, float c, float eps, float* rs) {
+    const int m = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    const int per = (groups + 3) >> 2;
+    const int g0 = part * per, g1 = min(g0 + per, groups);
+    float t = 0.f;
+    if (m < M) {
+        const float* row = ssq + (long)m * ld;
+        if ((per & 3) == 0 && (ld & 3) == 0 && g1 - g0 == per) {
+            for (int g = g0; g < g1; g += 4) {
+                const f32x4 v = *(const f32x4*)(row + g);
+                t = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(t, v[0]), v[1]), v[2]), v[3]);
+            }
+        } else {
+            for (int g = g0; g < g1; ++g) t = __fadd_rn(t, row[g]);
+        }
+    }
+    t = __fadd_rn(t, __shfl_xor(t, 1, 64));
+    t = __fadd_rn(t, __shfl_xor(t, 2, 64));
+    if (m < M && part == 0) rs[m] = 1.0f / sqrtf(t / c + eps);
+}
+
+extern "C" int uv_rms_scale_from_ssq(const float* ssq, long ld_ssq, int M, int groups, int C, float eps, float* rs, void* stream) {
+    UV_CHECK_ARG(ssq && rs && M > 0 && groups > 0 && C > 0 && ld_ssq >= groups, "uv_rms_scale_from_ssq: bad arguments");
+    UV_CHECK_ARG((((uintptr_t)ssq) & 15) == 0, "uv_rms_scale_from_ssq: ssq must be 16-byte aligned");
+    hipLaunchKernelGGL(rms_scale_from_ssq_kernel, dim3((M + 63) / 64), dim3(256), 0, (hipStream_t)stream, ssq, ld_ssq, M, groups, (float)C, eps, rs);
+    UV_CHECK_LAUNCH("uv_rms_scale_from_ssq");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row-wise L2 normalisation: out[r] = x[r] / max(||x[r]||_2, eps)  (torch.nn.functional.normalize(dim=-1), the cosine
 // scoring of the SigLIP2 ranker: models/BAGEL/eval_understanding.py:185,195). One wave per row.
 // ------------------------------------------------------------------------------------------------

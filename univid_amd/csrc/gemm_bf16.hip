@@ -30,15 +30,17 @@ static int launch_m_split(const GemmArgs& a, int epilogue, int main_cfg, hipStre
     at.A = a.A + m_main * a.lda;
     if (a.gate_tid) at.gate_tid = a.gate_tid + m_main;
     if (epilogue == UV_EPI_BF16_T) at.out = (bf16_t*)a.out + m_main;
-    else if (epilogue == UV_EPI_BF16 || epilogue == UV_EPI_GELU_BF16) at.out = (bf16_t*)a.out + m_main * a.ldo;
+    else if (epilogue == UV_EPI_BF16 || epilogue == UV_EPI_GELU_BF16 || epilogue == UV_EPI_BF16_SSQ) at.out = (bf16_t*)a.out + m_main * a.ldo;
     else at.out = (float*)a.out + m_main * a.ldo;
+    if (a.ssq) at.ssq = a.ssq + m_main * a.ld_ssq;
     const int rc = launch_by_cfg<F16>(am, epilogue, main_cfg, s);
     return rc ? rc : launch_by_cfg<F16>(at, epilogue, 12, s);
 }
 
 template <bool F16>
 static int gemm_entry(const void* A, long lda, const void* W, long ldw, const void* bias_bf16, int M, int N, int K, int epilogue,
-                      void* out, long ldo, const float* gate, const int32_t* gate_tid, long gate_stride, int tile_cfg, void* stream) {
+                      void* out, long ldo, const float* gate, const int32_t* gate_tid, long gate_stride, int tile_cfg, void* stream,
+                      float* ssq = nullptr, long ld_ssq = 0) {
     UV_CHECK_ARG(A && W && out, "uv_gemm_bf16_nt: null pointer");
     UV_CHECK_ARG(M > 0 && N > 0 && K > 0, "uv_gemm_bf16_nt: bad shape M=%d N=%d K=%d", M, N, K);
     UV_CHECK_ARG(K % UV_BK == 0, "uv_gemm_bf16_nt: K=%d must be a multiple of %d", K, UV_BK);
@@ -54,11 +56,14 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
     a.out = out; a.gate = gate; a.gate_tid = gate_tid;
     a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.gate_stride = gate_stride;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
+    a.ssq = ssq; a.ld_ssq = ld_ssq;
+    if (epilogue == UV_EPI_BF16_SSQ)
+        UV_CHECK_ARG(ssq && N % 32 == 0 && ld_ssq >= N / 32 && ldo % 8 == 0, "uv_gemm_bf16_nt_ssq: needs N %% 32 == 0, ld_ssq >= N / 32, ldo %% 8 == 0 (N=%d ld_ssq=%ld ldo=%ld)", N, ld_ssq, ldo);
     a.zeros = uv_zero_page();
     UV_CHECK_ARG(a.zeros, "uv_gemm_bf16_nt: zero page missing (call uv_init)");
     hipStream_t s = (hipStream_t)stream;
     if (tile_cfg == 0 && M >= 2048 && N >= 1024 && N % 256 == 0 && K % 128 == 0 && K >= 384 &&
-        (ldo % 8 == 0 || epilogue == UV_EPI_BF16_T || epilogue >= UV_EPI_F32_FROM_BF16)) {
+        (ldo % 8 == 0 || epilogue == UV_EPI_BF16_T || (epilogue >= UV_EPI_F32_FROM_BF16 && epilogue != UV_EPI_BF16_SSQ))) {
         // Large projections: 256x256 tiles on the PERSISTENT 8-wave ping-pong kernel (one workgroup per CU walking its tile
         // list). It takes whole tiles only; rows beyond the last multiple of 256 - and, when the tile count is just above a
         // whole number of rounds, the rows of that partial round - run as 128x128 tiles on the small-tile kernel.
@@ -85,6 +90,13 @@ extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw,
                                const float* gate, const int32_t* gate_tid, long gate_stride,
                                int tile_cfg, void* stream) {
     return gemm_entry<false>(A, lda, W, ldw, bias_bf16, M, N, K, epilogue, out, ldo, gate, gate_tid, gate_stride, tile_cfg, stream);
+}
+
+// UV_EPI_BF16 plus the output's sums of squares per aligned 32-column group (see include/univid_hip.h): the q projection whose RMSNorm is applied
+// by the attention kernel's prologue (uv_flash_attn_bf16_qnorm) instead of a pass of its own over q.
+extern "C" int uv_gemm_bf16_nt_ssq(const void* A, long lda, const void* W, long ldw, const void* bias_bf16, int M, int N, int K,
+                                   void* out, long ldo, float* ssq, long ld_ssq, int tile_cfg, void* stream) {
+    return gemm_entry<false>(A, lda, W, ldw, bias_bf16, M, N, K, UV_EPI_BF16_SSQ, out, ldo, nullptr, nullptr, 0, tile_cfg, stream, ssq, ld_ssq);
 }
 
 // The same GEMM with IEEE fp16 operands / bias / 16-bit outputs (fp32 accumulate): the SigLIP2 ranker's reference dtype
@@ -118,7 +130,7 @@ static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStrea
             const long t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
             // cost ~ rounds x tile area; 256x192 tiles carry 3/4 of the work of 256x256 at slightly lower efficiency
             const double c256 = (double)((t256 + 255) / 256) * 1.00, c192 = (double)((t192 + 255) / 256) * 0.78;
-            if (!F16 && N % 192 == 0 && c192 < c256 && K <= 4096) return launch_cfg<256, 192, 4, 4>(a, epilogue, s);
+            if (!F16 && N % 192 == 0 && c192 < c256 && K <= 4096 && epilogue != UV_EPI_BF16_SSQ) return launch_cfg<256, 192, 4, 4>(a, epilogue, s);
             return launch_cfg<256, 256, 4, 4, 2, F16>(a, epilogue, s);
         }
         case 1: if constexpr (!F16) return launch_cfg<128, 128, 2, 2>(a, epilogue, s); else break;

@@ -38,6 +38,7 @@ enum {
     UV_EPI_RESID_F32 = 3,      // x_f32   += float(bf16(acc + bias))
     UV_EPI_GATE_RESID_F32 = 4, // x_f32    = x + float(bf16(acc + bias)) * gate[tid[m]][n]
     UV_EPI_BF16_T = 5,         // outT_bf16[n][m] = bf16(acc + bias)   (V^T for attention)
+    UV_EPI_BF16_SSQ = 6,       // UV_EPI_BF16 + ssq[m][n / 32] = sum of float(out_bf16)^2 over each aligned group of 32 columns (uv_gemm_bf16_nt_ssq)
 };
 
 struct GemmArgs {
@@ -52,6 +53,8 @@ struct GemmArgs {
     int M, N, K;
     int tiles_m, tiles_n;
     int gm;                   // persistent kernel: height (in tiles) of the column groups the tile walk is made of
+    float* ssq;               // UV_EPI_BF16_SSQ: [M, ld_ssq] f32 partial sums of squares, one per 32-column group
+    long ld_ssq;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -122,6 +125,45 @@ __device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, cons
 }
 
 
+// Sum of squares of the 16-bit OUTPUT values of one aligned 32-column group (columns nb .. nb+31, nb % 32 == 0) of row mb + frow, from the
+// group's two fragments in the MFMA's layout (lane fq holds columns nb + 16 f + 4 fq + e of fragment f). ONE summation order, whatever
+// kernel and tile shape the group is computed in - so the value does not depend on the GEMM's schedule (tested bit for bit):
+//   quad sums   s_k = ((x0^2 + x1^2) + x2^2) + x3^2 over the 4 consecutive columns of quad k = 4 f + fq   (plain f32 multiplies and adds)
+//   lane        u_fq = s_fq + s_(4+fq)
+//   group       G = (u_0 + u_1) + (u_2 + u_3)        (two butterfly exchanges: every lane of the row ends with the same G)
+// v0 / v1: the fragment values AFTER the 16-bit rounding of the output, as f32. Returned in every lane.
+__device__ __forceinline__ float ssq_group32(const float (&v0)[4], const float (&v1)[4]) {
+    const float s0 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(v0[0], v0[0]), __fmul_rn(v0[1], v0[1])), __fmul_rn(v0[2], v0[2])), __fmul_rn(v0[3], v0[3]));
+    const float s1 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(v1[0], v1[0]), __fmul_rn(v1[1], v1[1])), __fmul_rn(v1[2], v1[2])), __fmul_rn(v1[3], v1[3]));
+    const float u = __fadd_rn(s0, s1);
+    const float t = __fadd_rn(u, __shfl_xor(u, 16, 64));
+    return __fadd_rn(t, __shfl_xor(t, 32, 64));
+}
+
+// UV_EPI_BF16_SSQ on two column-adjacent fragments, fragment-wise stores (any kernel, with bounds): the bf16 output of UV_EPI_BF16 and the
+// group's sum of squares. nb % 32 == 0. Rows / columns outside the matrix store nothing (their lanes still take part in the exchange).
+template <bool F16>
+__device__ __forceinline__ void epi_pair_ssq(const GemmArgs& p, int mb, int nb, const f32x4& a0, const f32x4& a1, int frow, int fq) {
+    const int m = mb + frow;
+    float v[2][4];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int n = min(nb + 16 * f + 4 * fq, p.N - 4);
+        const u32x2 bb = p.bias ? *(const u32x2*)(p.bias + n) : (u32x2){0u, 0u};
+        const f32x4& a = f ? a1 : a0;
+        v[f][0] = round16<F16>(a[0] + in16<F16>((bf16_t)(bb[0] & 0xffff)));
+        v[f][1] = round16<F16>(a[1] + in16<F16>((bf16_t)(bb[0] >> 16)));
+        v[f][2] = round16<F16>(a[2] + in16<F16>((bf16_t)(bb[1] & 0xffff)));
+        v[f][3] = round16<F16>(a[3] + in16<F16>((bf16_t)(bb[1] >> 16)));
+        if (m < p.M && nb + 16 * f + 4 * fq < p.N) {
+            u32x2 o = {pack16_2<F16>(v[f][0], v[f][1]), pack16_2<F16>(v[f][2], v[f][3])};
+            *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + nb + 16 * f + 4 * fq) = o;
+        }
+    }
+    const float g = ssq_group32(v[0], v[1]);
+    if (fq == 0 && m < p.M && nb < p.N) p.ssq[(long)m * p.ld_ssq + (nb >> 5)] = g;
+}
+
 // Two column-adjacent 16x16 fragments (columns nb .. nb+15 and nb+16 .. nb+31 of the same 16 rows) through the bf16 / GELU
 // epilogue with 16-BYTE stores: in the MFMA's layout a lane holds 4 consecutive columns (8 bytes of bf16) of each fragment; two
 // v_permlane16_swap exchange the halves between the lane groups fq = 0 <-> 1 and 2 <-> 3 so that every lane ends up with 8
@@ -130,9 +172,10 @@ __device__ __forceinline__ void epi_frag(const GemmArgs& p, int mb, int nb, cons
 // instructions, twice the segment. Whole tiles only (the persistent kernel); values are those of epi_frag.
 template <int EPI, bool F16>
 __device__ __forceinline__ void epi_pair16(const GemmArgs& p, int mb, int nb, const f32x4& a0, const f32x4& a1, int frow, int fq) {
-    static_assert(EPI == UV_EPI_BF16 || EPI == UV_EPI_GELU_BF16, "16-bit row-major outputs only");
+    static_assert(EPI == UV_EPI_BF16 || EPI == UV_EPI_GELU_BF16 || EPI == UV_EPI_BF16_SSQ, "16-bit row-major outputs only");
     const int m = mb + frow;
     uint32_t w[2][2];
+    float r[2][4];      // UV_EPI_BF16_SSQ: the rounded outputs as f32
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const int n = nb + 16 * f + 4 * fq;
@@ -144,8 +187,16 @@ __device__ __forceinline__ void epi_pair16(const GemmArgs& p, int mb, int nb, co
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f32(round16<F16>(v[e]));
         }
+        if (EPI == UV_EPI_BF16_SSQ) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[f][e] = v[e] = round16<F16>(v[e]);
+        }
         w[f][0] = pack16_2<F16>(v[0], v[1]);
         w[f][1] = pack16_2<F16>(v[2], v[3]);
+    }
+    if (EPI == UV_EPI_BF16_SSQ) {
+        const float g = ssq_group32(r[0], r[1]);
+        if (fq == 0) p.ssq[(long)m * p.ld_ssq + (nb >> 5)] = g;
     }
     // swap lanes 16-31 / 48-63 of the first fragment's words with lanes 0-15 / 32-47 of the second's
     const auto s0 = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
@@ -386,6 +437,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
                 av[j * TN + i] = acc[i][j];
             }
         epi_rmw_pipe<EPI, NF, (NF >= 8 ? 4 : 2), F16>(p, mb, nb, av, frow, fq);
+    } else if constexpr (EPI == UV_EPI_BF16_SSQ) {
+        static_assert(TN % 2 == 0 && (BN / WN) % 32 == 0, "UV_EPI_BF16_SSQ needs whole 32-column groups per wave");
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; i += 2)
+                epi_pair_ssq<F16>(p, m0 + wm * (BM / WM) + j * 16, n0 + wn * (BN / WN) + i * 16, acc[i][j], acc[i + 1][j], frow, fq);
     } else {
 #pragma unroll
         for (int j = 0; j < TM; ++j)
@@ -695,6 +753,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
                         av[f] = acc[hn][hm][i][j];
                     }
         epi_rmw_pipe<EPI, 32, 8, F16>(p, mb, nb, av, frow, fq);
+    } else if constexpr (EPI == UV_EPI_BF16_SSQ) {
+#pragma unroll
+        for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int hn = 0; hn < 2; ++hn)
+                    epi_pair_ssq<F16>(p, m0 + hm * 128 + wr * 64 + j * 16, n0 + hn * 128 + wc * 32, acc[hn][hm][0][j], acc[hn][hm][1][j], frow, fq);
     } else {
 #pragma unroll
         for (int hm = 0; hm < 2; ++hm)
@@ -844,7 +910,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_persist_kernel(GemmArgs p) 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-        } else if constexpr (EPI == UV_EPI_BF16 || EPI == UV_EPI_GELU_BF16) {
+        } else if constexpr (EPI == UV_EPI_BF16 || EPI == UV_EPI_GELU_BF16 || EPI == UV_EPI_BF16_SSQ) {
 #pragma unroll
             for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
@@ -901,6 +967,7 @@ static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
         UV_LAUNCH8(UV_EPI_RESID_F32)
         UV_LAUNCH8(UV_EPI_GATE_RESID_F32)
         UV_LAUNCH8(UV_EPI_BF16_T)
+        UV_LAUNCH8(UV_EPI_BF16_SSQ)
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown epilogue %d", epi);
             return -1;
@@ -914,7 +981,7 @@ template <bool F16 = false>
 static int launch_8ph_persist(const GemmArgs& a0, int epi, hipStream_t stream) {
     GemmArgs a = a0;
     UV_CHECK_ARG(a.M % 256 == 0 && a.N % 256 == 0, "uv_gemm_bf16_nt: the persistent kernel needs whole 256x256 tiles (M=%d N=%d)", a.M, a.N);
-    UV_CHECK_ARG(a.ldo % 8 == 0 || (epi != UV_EPI_BF16_T && epi != UV_EPI_BF16 && epi != UV_EPI_GELU_BF16),
+    UV_CHECK_ARG(a.ldo % 8 == 0 || (epi != UV_EPI_BF16_T && epi != UV_EPI_BF16 && epi != UV_EPI_GELU_BF16 && epi != UV_EPI_BF16_SSQ),
                  "uv_gemm_bf16_nt: the persistent kernel stores 16 bytes per lane: ldo=%ld must be a multiple of 8 elements", a.ldo);
     a.tiles_m = a.M / 256;
     a.tiles_n = a.N / 256;
@@ -942,6 +1009,7 @@ static int launch_8ph_persist(const GemmArgs& a0, int epi, hipStream_t stream) {
         UV_LAUNCH8P(UV_EPI_RESID_F32)
         UV_LAUNCH8P(UV_EPI_GATE_RESID_F32)
         UV_LAUNCH8P(UV_EPI_BF16_T)
+        UV_LAUNCH8P(UV_EPI_BF16_SSQ)
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown epilogue %d", epi);
             return -1;
@@ -972,6 +1040,16 @@ static int launch_cfg(const GemmArgs& a0, int epi, hipStream_t stream) {
         UV_LAUNCH(UV_EPI_RESID_F32)
         UV_LAUNCH(UV_EPI_GATE_RESID_F32)
         UV_LAUNCH(UV_EPI_BF16_T)
+        case UV_EPI_BF16_SSQ:
+            if constexpr ((BN / WN) % 32 == 0) {
+                auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, UV_EPI_BF16_SSQ, NS, F16>;
+                UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+                break;
+            } else {
+                uv_set_error("uv_gemm_bf16_nt_ssq: this tile shape has no whole 32-column groups per wave");
+                return -1;
+            }
         default:
             uv_set_error("uv_gemm_bf16_nt: unknown epilogue %d", epi);
             return -1;

@@ -192,6 +192,8 @@ class WanCrossAttention(WanSelfAttention):
     """Text cross-attention (model.py:158-180). The class name and the (x, context, context_lens) signature are
     part of UniVid's contract: Wan22ContextWrapper finds modules by `__class__.__name__ == 'WanCrossAttention'`
     and replaces `module.forward` with a closure that rescales `context` (model_pipeline.py:1745-1807)."""
+    fuse_q_norm = True      # norm_q inside the attention kernel's Q prologue instead of a pass over q (A/B switch; same arithmetic but for
+                            # the summation order of the row's mean square)
 
     def _context_kv(self, ctx, Lc, batch, kv_key, out=None):
         """k = norm_k(Wk ctx) [batch*Lc, C] and V^T = (Wv ctx)^T of the embedded context (model.py:170-172). They depend on the
@@ -232,11 +234,22 @@ class WanCrossAttention(WanSelfAttention):
         C, H, D = self.dim, self.num_heads, self.head_dim
         p = self._prep
         dev = hq.device
-        ql = torch.empty(batch * L, C, dtype=BF16, device=dev)
-        _lib.gemm_bf16(hq, p["q"].w, p["q"].b, ql, EPI_BF16, M=batch * L)
-        _lib.rmsnorm_rope(ql, ql, self.norm_q.weight, batch * L, C, D, self.eps)
+        M = batch * L
+        ql = torch.empty(M, C, dtype=BF16, device=dev)
         kl, vt = self._context_kv(ctx, Lc, batch, kv_key)
-        att = torch.empty(batch * L, C, dtype=BF16, device=dev)
+        att = torch.empty(M, C, dtype=BF16, device=dev)
+        if self.fuse_q_norm and C % 32 == 0:
+            # norm_q without a pass of its own over q (round 5): the q GEMM's epilogue leaves each output row's sums of squares per 32-column
+            # group, a tiny kernel turns them into the row scale 1 / sqrt(mean + eps), and the attention kernel's Q prologue applies scale and
+            # weight with WanRMSNorm's rounding points (model.py:82-85) while it loads the raw projection
+            ssq = torch.empty(M, C // 32, dtype=torch.float32, device=dev)
+            rs = torch.empty(M, dtype=torch.float32, device=dev)
+            _lib.gemm_bf16_ssq(hq, p["q"].w, p["q"].b, ql, ssq, M=M)
+            _lib.rms_scale_from_ssq(ssq, rs, M, C, self.eps)
+            _lib.flash_attn(ql, kl, vt, att, L, Lc, H, D, 1.0 / math.sqrt(D), batch=batch, q_rs=rs, q_weight=self.norm_q.weight)
+            return att
+        _lib.gemm_bf16(hq, p["q"].w, p["q"].b, ql, EPI_BF16, M=M)
+        _lib.rmsnorm_rope(ql, ql, self.norm_q.weight, M, C, D, self.eps)
         _lib.flash_attn(ql, kl, vt, att, L, Lc, H, D, 1.0 / math.sqrt(D), batch=batch)
         return att
 
