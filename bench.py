@@ -321,8 +321,8 @@ def ranker_probe(device, frames=64, reps=9):
     """BASELINE.json config 5 (reference models/BAGEL/eval_understanding.py:171-206): SigLIP2-base patch16 encode of 64 keyframes per
     video for the Pyramid-Reflection ranker, fp16 as the reference loads it (:172), random-init weights of the siglip2-base geometry
     (768-d, 12 layers, 12 heads x 64, 256 patches of 16x16x3; NaFlex inputs pixel_values [64, 256, 768], full masks, 16x16 grids), one
-    64-token text query: Siglip2Scorer.rank_frames = text tower + vision tower on the 64 frames + cosine top-8, replayed from the
-    vision tower's HIP graph (its default). frames/s = 64 / median wall time of `reps` calls. FLOPs per frame: 12 layers x ((8 h^2 + 4 h f)
+    64-token text query: Siglip2Scorer.rank_frames = text tower + vision tower on the 64 frames + cosine top-8 (eager launches: a HIP-graph replay of
+    the tower measures the same at this size, profiles/r02_ranker_bench.md). frames/s = 64 / median wall time of `reps` calls. FLOPs per frame: 12 layers x ((8 h^2 + 4 h f)
     per token x 256 + attention 4 L^2 h) + patch embedding + pooling head = 46.5 GFLOP. OUTSIDE the metric's timed region."""
     from univid_amd.understanding import Siglip2Model, Siglip2Scorer
     V = dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, num_channels=3, patch_size=16,
@@ -363,7 +363,7 @@ def ranker_probe(device, frames=64, reps=9):
         res[name] = {"ms": round(t * 1e3, 3), "frames_per_sec": round(B / t, 1), "tflops": round(B * flops_frame / t / 1e12, 1),
                      "frac_fp16_peak": round(B * flops_frame / t / 1e12 / PEAK_BF16_TFLOPS, 4)}
     return {"workload": f"BASELINE config 5: SigLIP2-base patch16, {B} keyframes x 256 patches, fp16, random-init; rank_frames = text query + {B} frames + cosine top-8 "
-                        "(eval_understanding.py:171-206); image_features = the vision tower alone; median of %d calls, HIP-graph replay of the tower" % reps,
+                        "(eval_understanding.py:171-206); image_features = the vision tower alone; median of %d calls" % reps,
             "metric": "ranker_frames_per_sec", "value": res["rank_frames"]["frames_per_sec"], "unit": "frames/s", "dtype": "fp16",
             "gflop_per_frame": round(flops_frame / 1e9, 1), **res,
             "note": "launch/latency-bound at this size (2.9 TFLOP per call): the fraction of the fp16 MFMA peak is reported, not a target"}
