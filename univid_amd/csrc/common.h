@@ -110,6 +110,21 @@ __device__ __forceinline__ float gelu_tanh_f32(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// The same function on two values at once with PACKED f32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two lanes' worth of work per
+// issue slot; the two exponentials and reciprocals stay scalar instructions). Each component is computed by exactly the operations of
+// gelu_tanh_f32 (a packed instruction is two independent IEEE operations): bit-identical results. For epilogues, where no MFMA is in
+// flight beside them (packed f32 VALU next to MFMAs costs issue cycles: MI355X_MICROARCH.md).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_tanh_f32x2(f32x2 x) {
+    const f32x2 kA = {-2.3022081986f, -2.3022081986f}, kB = {-0.1029432396f, -0.1029432396f}, one = {1.0f, 1.0f};
+    const f32x2 q = __builtin_elementwise_fma(x * x, kB, kA);
+    const f32x2 t = x * q;
+    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    const f32x2 d = one + e;
+    const f32x2 c = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return x * c;
+}
+
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
 
 // Developer options (include/univid_hip.h: uv_set_option). Process-wide relaxed atomics: set explicitly through the C ABI, never
