@@ -474,8 +474,12 @@ class WanTI2V:
         if self._progress is None:
             return
         host_ctr = self._progress[1]
+        waited = 0
         while self._steps_issued - int(host_ctr[0]) >= self.max_steps_in_flight:
             time.sleep(1e-3)
+            waited += 1
+            if waited % 60000 == 0:      # a minute without progress: let a device fault surface as an error instead of napping forever
+                torch.cuda.synchronize(self.device)
 
     def _noise(self, shape, seed):
         seed = seed if seed >= 0 else random.randint(0, sys.maxsize)
