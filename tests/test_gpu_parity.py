@@ -1148,11 +1148,28 @@ def test_graph_runner_serves_new_prompts_without_recapture_and_never_goes_stale(
         ctx2[0].mul_(-0.5)                                 # in-place edit bumps the version: refreshed
         d3 = pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, graph=True)
         assert pipe._runner is r1 and torch.equal(d3, b_graph)
-        # i2v is another graph (other token -> timestep map); t2v afterwards captures again and still serves the current prompt
+        # i2v is another graph (other token -> timestep map); both stay captured (WanTI2V.max_graph_runners = 2): going back to t2v replays
+        # the FIRST graph, with the prompt of THAT call, and alternating the two modes never captures again
         z = g["z"].to(DEV)
         e_graph = pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, z=z, graph=True).clone()
-        assert pipe._runner is not r1
+        r2 = pipe._runner
+        assert r2 is not r1
         assert torch.equal(e_graph, pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, z=z, graph=False))
+        ctx3 = [g["ctx"].to(DEV).clone()]
+        f_graph = pipe.denoise(g["noise"].to(DEV), ctx3, ctxn2, *args, graph=True)
+        assert pipe._runner is r1 and torch.equal(f_graph, a_graph), "back to t2v: the first graph, the current prompt"
+        assert torch.equal(pipe.denoise(g["noise"].to(DEV), ctx2, ctxn2, *args, z=z, graph=True), e_graph) and pipe._runner is r2
+        # a third shape evicts the least recently used (the t2v graph); the i2v graph survives
+        shorter = g["noise"].to(DEV)[:, :1].contiguous()
+        s_graph = pipe.denoise(shorter, ctx3, ctxn2, *args, graph=True).clone()
+        assert len(pipe._runners) == 2 and r2 in pipe._runners.values() and r1 not in pipe._runners.values()
+        assert torch.equal(s_graph, pipe.denoise(shorter, ctx3, ctxn2, *args, graph=False))
+        assert torch.equal(pipe.denoise(g["noise"].to(DEV), ctx3, ctxn2, *args, graph=True), a_graph), "re-captured after eviction"
+        # new prepared weights: every held graph is dropped at the next graph-mode call
+        m._prep_gen += 1
+        assert torch.equal(pipe.denoise(g["noise"].to(DEV), ctx3, ctxn2, *args, graph=True), a_graph) and len(pipe._runners) == 1
+        pipe._runner = None
+        assert pipe._runner is None and not pipe._runners
 
 
 def test_sampler_dpmpp_trajectories_vs_golden():

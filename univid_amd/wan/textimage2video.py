@@ -255,7 +255,11 @@ class WanTI2V:
         self.patch_size = config.patch_size
         self.sp_size = 1
         self.cfgp = None
-        self._runner = None      # cached _GraphedPair (HIP graph of the CFG pair's forward) of the last graph-mode denoise
+        # captured _GraphedPair runners (HIP graph of the CFG pair's forward), most recently used last: a service that alternates t2v and i2v
+        # (or two clip lengths) replays both instead of re-capturing on every switch (a capture = one eager pair forward + the capture pass,
+        # 0.65 s at L = 11 440 - 13 ms per step of a 50-step generation). Each holds its graph's activation pool; the oldest goes first
+        self._runners = collections.OrderedDict()
+        self.max_graph_runners = 2
         self._progress, self._steps_issued = None, 0
         self.max_steps_in_flight = 4       # sampler steps the host may queue ahead of the GPU (WanTI2V._steps)
         self.text_weight_schedule = None   # object with next_pair() / rows(text_len) / layers: UniVid's dynamic text weight, native
@@ -287,6 +291,17 @@ class WanTI2V:
             # runs the same sample (same seed) and holds the full result after each forward
             self.model.enable_sequence_parallel()
             self.sp_size = self.model.sp.size
+
+    @property
+    def _runner(self):
+        """The runner of the last graph-mode denoise (None before the first)."""
+        return next(reversed(self._runners.values())) if self._runners else None
+
+    @_runner.setter
+    def _runner(self, value):
+        if value is not None:
+            raise ValueError("_runner can only be cleared")
+        self._runners.clear()
 
     def enable_cfg_parallel(self, group=None):
         """Extension: the ranks of `group` (exactly 2) split the cond / uncond forwards of every step and exchange
@@ -377,12 +392,16 @@ class WanTI2V:
             # one captured graph per (latent shape, mode, prepared weights); the prompt travels through the runner's own context buffers,
             # recomputed in place at the start of every call (_GraphedPair.refresh): no recapture for a new prompt, nothing to go stale
             key = (tuple(latent.shape), i2v, self.model._prep_gen, self.model.text_len)
-            runner = self._runner if (self._runner is not None and self._runner.key == key) else None
+            runner = self._runners.pop(key, None)
             if runner is None:
-                self._runner = None      # frees the old graph's pool before the new capture
-                runner = self._runner = _GraphedPair(self.model, latent, context, context_null, seq_len, base_mask if i2v else None, key)
+                for stale in [k for k in self._runners if k[2:] != key[2:]]:
+                    del self._runners[stale]         # prepared weights / text length changed: those graphs can never be asked for again
+                while len(self._runners) >= max(1, self.max_graph_runners):
+                    self._runners.popitem(last=False)   # frees the oldest graph's pool before the new capture
+                runner = _GraphedPair(self.model, latent, context, context_null, seq_len, base_mask if i2v else None, key)
             else:
                 runner.refresh(context, context_null)
+            self._runners[key] = runner
         try:
             return self._steps(sched, timesteps, latent, context, context_null, guide_scale, z, mask2, base_mask, seq_len, record, runner, tws)
         finally:
