@@ -570,3 +570,54 @@ def test_ffn0_row_padding_never_adds_a_round_of_tiles():
     for L in range(2048, 60000, 997):
         Lp = M._ffn0_rows(L, 14336, "cpu-test")
         assert Lp == L or (Lp % 256 == 0 and 0 < Lp - L < 256 and -(-(Lp // 256 * 56) // 256) == -(-(L // 256 * 56) // 256))
+
+
+def test_graph_runner_cache_policy():
+    """WanTI2V keeps the `max_graph_runners` most recently used captured graphs (host logic only - stand-ins for the runners; the replay
+    itself is tests/test_gpu_parity.py::test_graph_runner_serves_new_prompts_without_recapture_and_never_goes_stale): a hit moves the
+    runner to the most-recently-used end and builds nothing; a miss evicts the least recently used BEFORE building (the old graph's pool is
+    free when the new capture allocates); another prepared-weights generation or text_len drops every held runner; a failing capture
+    leaves nothing behind; `_runner` reads the last used one and can only be cleared."""
+    import collections
+    pipe = textimage2video.WanTI2V.__new__(textimage2video.WanTI2V)
+    pipe._runners, pipe.max_graph_runners = collections.OrderedDict(), 2
+    assert pipe._runner is None
+    built, alive = [], set()
+
+    class Runner:
+        def __init__(self, name):
+            self.name = name
+            alive.add(name)
+
+    def make(name, expect_alive=None):
+        def f():
+            if expect_alive is not None:
+                assert {r.name for r in pipe._runners.values()} == expect_alive, "eviction must happen before the capture"
+            built.append(name)
+            return Runner(name)
+        return f
+    t2v, i2v, short = ((48, 13, 44, 80), False, 3, 512), ((48, 13, 44, 80), True, 3, 512), ((48, 4, 44, 80), False, 3, 512)
+    a, fresh = pipe._runner_for(t2v, make("t2v"))
+    assert fresh and pipe._runner is a
+    b, fresh = pipe._runner_for(i2v, make("i2v", {"t2v"}))
+    assert fresh and pipe._runner is b and list(pipe._runners) == [t2v, i2v]
+    a2, fresh = pipe._runner_for(t2v, make("never"))
+    assert a2 is a and not fresh and pipe._runner is a and list(pipe._runners) == [i2v, t2v] and built == ["t2v", "i2v"]
+    c, fresh = pipe._runner_for(short, make("short", {"t2v"}))             # i2v is the least recently used: gone before the capture
+    assert fresh and list(pipe._runners) == [t2v, short]
+    # a capture that fails: the eviction it needed has happened, nothing is stored under its key
+    def boom():
+        raise RuntimeError("capture failed")
+    with pytest.raises(RuntimeError):
+        pipe._runner_for(i2v, boom)
+    assert i2v not in pipe._runners and list(pipe._runners) == [short]
+    # new prepared weights (generation 4): every held graph belongs to the old ones
+    d, fresh = pipe._runner_for(((48, 13, 44, 80), False, 4, 512), make("regen", set()))
+    assert fresh and len(pipe._runners) == 1 and pipe._runner is d
+    pipe.max_graph_runners = 0                                              # never below one: the runner in use is always held
+    e, _ = pipe._runner_for(((48, 13, 44, 80), True, 4, 512), make("one", set()))
+    assert list(pipe._runners.values()) == [e]
+    with pytest.raises(ValueError):
+        pipe._runner = e
+    pipe._runner = None
+    assert pipe._runner is None and not pipe._runners

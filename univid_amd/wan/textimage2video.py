@@ -292,6 +292,22 @@ class WanTI2V:
             self.model.enable_sequence_parallel()
             self.sp_size = self.model.sp.size
 
+    def _runner_for(self, key, make):
+        """The cached runner of `key` = (latent shape, i2v, prepared-weights generation, text_len), moved to the most-recently-used end, or
+        `make()` stored under it. Returns (runner, fresh). Before a capture: runners of other prepared weights / another text_len are
+        dropped (they can never be asked for again) and the least recently used ones go until there is room - their graphs' pools are
+        freed BEFORE the new capture allocates its own. A `make()` that raises leaves nothing behind under `key`."""
+        runner = self._runners.pop(key, None)
+        fresh = runner is None
+        if fresh:
+            for stale in [k for k in self._runners if k[2:] != key[2:]]:
+                del self._runners[stale]
+            while len(self._runners) >= max(1, self.max_graph_runners):
+                self._runners.popitem(last=False)
+            runner = make()
+        self._runners[key] = runner
+        return runner, fresh
+
     @property
     def _runner(self):
         """The runner of the last graph-mode denoise (None before the first)."""
@@ -392,16 +408,10 @@ class WanTI2V:
             # one captured graph per (latent shape, mode, prepared weights); the prompt travels through the runner's own context buffers,
             # recomputed in place at the start of every call (_GraphedPair.refresh): no recapture for a new prompt, nothing to go stale
             key = (tuple(latent.shape), i2v, self.model._prep_gen, self.model.text_len)
-            runner = self._runners.pop(key, None)
-            if runner is None:
-                for stale in [k for k in self._runners if k[2:] != key[2:]]:
-                    del self._runners[stale]         # prepared weights / text length changed: those graphs can never be asked for again
-                while len(self._runners) >= max(1, self.max_graph_runners):
-                    self._runners.popitem(last=False)   # frees the oldest graph's pool before the new capture
-                runner = _GraphedPair(self.model, latent, context, context_null, seq_len, base_mask if i2v else None, key)
-            else:
+            runner, fresh = self._runner_for(key, lambda: _GraphedPair(self.model, latent, context, context_null, seq_len,
+                                                                       base_mask if i2v else None, key))
+            if not fresh:
                 runner.refresh(context, context_null)
-            self._runners[key] = runner
         try:
             return self._steps(sched, timesteps, latent, context, context_null, guide_scale, z, mask2, base_mask, seq_len, record, runner, tws)
         finally:
