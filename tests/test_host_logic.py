@@ -621,3 +621,25 @@ def test_graph_runner_cache_policy():
         pipe._runner = e
     pipe._runner = None
     assert pipe._runner is None and not pipe._runners
+
+
+def test_fusion_pipeline_config_only_construction_refuses_loudly(tmp_path):
+    """CrossAttentionFusionPipeline(config) as inference.py:196 calls it (model_pipeline.py:2112-2131): a missing checkpoint directory is
+    the reference's FileNotFoundError (:2178-2180); an enabled BAGEL extraction without a registered extractor is an error naming
+    `register_bagel_extractor`, never a silent stub; the registered factory receives the reference's four keyword arguments (:2153-2158);
+    a GPU index this process does not have is named by its config field. No GPU is touched."""
+    from univid_amd.model_pipeline import CrossAttentionConfig, CrossAttentionFusionPipeline, register_bagel_extractor
+    with pytest.raises(FileNotFoundError, match="Wan2.2 model path not found"):
+        CrossAttentionFusionPipeline(CrossAttentionConfig(wan_model_path=str(tmp_path / "missing")))
+    cfg = CrossAttentionConfig(wan_model_path=str(tmp_path), bagel_model_path="/m/bagel", bagel_gpu=0, wan_gpu=0, cross_attn_gpu=0)
+    prev = register_bagel_extractor(None)
+    try:
+        with pytest.raises(RuntimeError, match="register_bagel_extractor"):
+            CrossAttentionFusionPipeline(cfg)
+        seen = {}
+        assert register_bagel_extractor(lambda **kw: seen.update(kw) or object()) is None
+        with pytest.raises(RuntimeError, match="cross_attn_gpu"):      # 0 GPUs here: the next thing the constructor needs
+            CrossAttentionFusionPipeline(cfg)
+        assert seen == dict(model_path="/m/bagel", device_id=0, use_bfloat16=True, config=cfg)
+    finally:
+        register_bagel_extractor(prev)

@@ -210,6 +210,17 @@ class Wan22ContextWrapper:
         """The lifetime of the forward counter = one generation (:1851-1876): reset to 0, advanced by every DiT forward of the loop
         that runs inside, removed afterwards. native: the loop reads it through WanTI2V.text_weight_schedule; otherwise a counting
         closure is re-assigned as the DiT's `forward`, as in the reference."""
+        if self.native:
+            # the native schedule exists only inside WanTI2V.denoise, which reads `text_weight_schedule`: a wrapped pipeline without that
+            # attribute (duck-typed / foreign) would silently generate with NO text weight, and a foreign re-assigned `forward` on the
+            # DiT or a cross-attention makes the loop take its generic path, which does not read the schedule either
+            if not hasattr(self.original_pipeline, "text_weight_schedule"):
+                raise TypeError(f"{type(self.original_pipeline).__name__} does not read a native text-weight schedule (no `text_weight_schedule` "
+                                f"attribute): wrap it with Wan22ContextWrapper(..., native=False) to install the reference's forward closures")
+            if "forward" in self.dit_model.__dict__ or any("forward" in m.__dict__ for m in self.dit_model.modules()
+                                                           if m.__class__.__name__ == "WanCrossAttention"):
+                raise RuntimeError("a `forward` re-assigned by someone else is installed on the DiT / a WanCrossAttention: the loop would run "
+                                   "its generic path and drop the native text-weight schedule - remove it or use native=False")
         self.sampling_step_counter = 0
         if self.native:
             self.original_pipeline.text_weight_schedule = _TextWeightSchedule(self)
@@ -296,31 +307,95 @@ class ContextProjector(torch.nn.Module):
         return out
 
 
-class CrossAttentionFusionPipeline:
-    """model_pipeline.py:2110-3230, inference side. Components are injected:
+_BAGEL_EXTRACTOR_FACTORY: Optional[Callable] = None
 
-        wan_pipeline     a univid_amd WanTI2V (DiT + VAE + text encoder hook-up)          - the hot path; the dynamic text weight
-                         rides on it as data (Wan22ContextWrapper native=True): stacked CFG pair + HIP-graph replay stay in use
-        bagel_extractor  object with extract_semantic_tokens(text, image) -> [1, L, 3584]  - off the hot path (stub OK)
-        context_projector callable tokens -> list[[512, 4096]]                             - off the hot path (stub OK)
+
+def register_bagel_extractor(factory: Optional[Callable]):
+    """The ONE hook-up point of the BAGEL-7B semantic extractor (reference `BagelSemanticExtractor`, model_pipeline.py:837-1503: a
+    7 B multimodal LLM, SURVEY.md section 2 row 14 - outside the denoise hot path and not rebuilt here). `factory` is called by
+    `CrossAttentionFusionPipeline(config)` exactly as the reference constructs its extractor (:2153-2158):
+
+        factory(model_path=config.bagel_model_path, device_id=config.bagel_gpu, use_bfloat16=config.use_bfloat16, config=config)
+
+    and must return an object with `extract_semantic_tokens(text, image_or_None) -> Tensor[1, L, bagel_hidden_dim]`
+    (:1240). Passing the reference's own class registers the reference's extractor unchanged. `None` un-registers. Returns the
+    previous factory."""
+    global _BAGEL_EXTRACTOR_FACTORY
+    prev, _BAGEL_EXTRACTOR_FACTORY = _BAGEL_EXTRACTOR_FACTORY, factory
+    return prev
+
+
+class CrossAttentionFusionPipeline:
+    """model_pipeline.py:2110-3230, inference side: `CrossAttentionFusionPipeline(config)` as inference.py:196 constructs it.
+
+    From `config` alone the constructor composes what the reference's `_initialize_components` (:2151-2174) composes:
+
+        .wan_pipeline       WanTI2V(wan_config, checkpoint_dir=config.wan_model_path, device_id=config.wan_gpu)    (:2193-2204) - the
+                            diffusers-layout DiT, Wan2.2_VAE.pth and the umT5 .pth + tokenizer of that directory, all on the HIP path
+        .context_projector  the native ContextProjector(config) on cuda:{config.cross_attn_gpu}                     (:2160-2161) - an
+                            nn.Module with the reference's tree, so inference.py:227-236's load_state_dict works
+        .bagel_extractor    the registered factory's object (register_bagel_extractor) when config.enable_bagel_extraction  (:2153-2158)
+        .lora_manager       LoRAManager(config) when config.use_lora                                                (:2117)
+        .dit_model / .vae_model / .wan_wrapper / .text_encoder                                                      (:2206-2207,2166)
+
+    Every component can instead be INJECTED (tests, services that already hold a WanTI2V): wan_pipeline=, bagel_extractor=,
+    context_projector=. `wan_config` is the WAN_CONFIGS['ti2v-5B'] counterpart (TI2VConfig); a subclass names other checkpoint
+    files / a width-reduced VAE or T5. Differences from the reference, on purpose: a missing extractor is an error naming the
+    registration point, never a stub; the reference's fresh trainable adapters (`_apply_lora_to_dit`, :2254-2297) are training-side -
+    an inference adapter arrives through `lora_manager.load_lora_weights` (inference.py:218-224); generation errors propagate.
     """
 
     def __init__(self, config: CrossAttentionConfig, wan_pipeline: Optional[WanTI2V] = None, bagel_extractor=None,
-                 context_projector: Optional[Callable] = None, save_fn: Optional[Callable] = None, native_text_weight: bool = True):
+                 context_projector: Optional[Callable] = None, save_fn: Optional[Callable] = None, native_text_weight: bool = True,
+                 wan_config=TI2VConfig):
         self.config = config
         self.logger = logging.getLogger("univid_amd.pipeline")
-        if wan_pipeline is None:
-            raise ValueError("pass wan_pipeline=WanTI2V(...): checkpoints cannot be discovered offline")
-        self.wan_pipeline = wan_pipeline
-        self.bagel_extractor = bagel_extractor
-        self.context_projector = context_projector
         # model_pipeline.py:2117: inference.py:218-224 calls `pipeline.lora_manager.load_lora_weights(path, pipeline.dit_model)`
         self.lora_manager = LoRAManager(config, self.logger) if getattr(config, "use_lora", False) else None
+        if wan_pipeline is None and not os.path.exists(config.wan_model_path):     # :2178-2180, checked before anything is built
+            raise FileNotFoundError(f"Wan2.2 model path not found: {config.wan_model_path}")
+        if bagel_extractor is None and getattr(config, "enable_bagel_extraction", True) and wan_pipeline is None:
+            # the injected form keeps its meaning (no extractor given = plain text-encoder context); the config-only form follows the
+            # reference, which always builds one (:2153)
+            if _BAGEL_EXTRACTOR_FACTORY is None:
+                raise RuntimeError(
+                    "config.enable_bagel_extraction is set and no BAGEL extractor is available: call "
+                    "univid_amd.model_pipeline.register_bagel_extractor(factory) first (factory(model_path=, device_id=, use_bfloat16=, "
+                    "config=) -> object with extract_semantic_tokens(text, image)), pass bagel_extractor=, or set "
+                    "enable_bagel_extraction=False to generate from the text encoder's context alone")
+            bagel_extractor = _BAGEL_EXTRACTOR_FACTORY(model_path=config.bagel_model_path, device_id=config.bagel_gpu,
+                                                       use_bfloat16=config.use_bfloat16, config=config)
+        self.bagel_extractor = bagel_extractor
+        if context_projector is None and wan_pipeline is None:
+            self._check_gpu("cross_attn_gpu")
+            context_projector = ContextProjector(config).to(f"cuda:{config.cross_attn_gpu}").eval()
+        self.context_projector = context_projector
+        if wan_pipeline is None:
+            wan_pipeline = self._initialize_wan22(wan_config)
+        self.wan_pipeline = wan_pipeline
         self.dit_model = wan_pipeline.model
         self.vae_model = wan_pipeline.vae
+        self.text_encoder = wan_pipeline.text_encoder
         # native_text_weight=False: the reference's closures on the model's generic path (kept as the comparison the tests and bench use)
-        self.wan_wrapper = Wan22ContextWrapper(wan_pipeline, context_projector, self.logger, config, native=native_text_weight)
+        self.wan_wrapper = Wan22ContextWrapper(wan_pipeline, self.context_projector, self.logger, config, native=native_text_weight)
         self.save_fn = save_fn
+
+    def _check_gpu(self, field_name):
+        idx, n = getattr(self.config, field_name), torch.cuda.device_count()
+        if not 0 <= idx < n:
+            raise RuntimeError(f"config.{field_name} = {idx}, but this process sees {n} GPU(s): the reference's defaults place BAGEL / Wan / "
+                               f"the projector on cuda:0 / 1 / 2 (inference.py:43-45); on one MI355X (288 GB) set all three to 0")
+
+    def _initialize_wan22(self, wan_config):
+        """:2176-2243. WanTI2V from the checkpoint directory. `skip_t5_loading` only moves the reference's T5 to the CPU (t5_cpu=True,
+        :2186-2191, the encoder is still what produces the context); here the encoder runs on the GPU either way (288 GB)."""
+        path = self.config.wan_model_path
+        self._check_gpu("wan_gpu")
+        try:
+            return WanTI2V(config=wan_config, checkpoint_dir=path, device_id=self.config.wan_gpu, rank=0, t5_fsdp=False, dit_fsdp=False,
+                           use_sp=False)
+        except Exception as e:
+            raise RuntimeError(f"Wan2.2 initialization failed: {e}") from e
 
     def generate_video_with_bagel_context(self, text: str, image=None, **kwargs):
         """:2577-2655. Returns (video [3, T, H, W] in [-1, 1], path | None). Extra keyword `prompt_embeds` /

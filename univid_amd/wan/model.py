@@ -311,6 +311,8 @@ class WanAttentionBlock(nn.Module):
         Lf = _ffn0_rows(L, self.ffn_dim, dev)
         h_full = torch.empty(Lf, C, dtype=BF16, device=dev)
         h = h_full[:L]
+        # NOTE for consumers of `mid` (ffn.0's output, below): its rows >= L are the GELU of whatever the allocator left in h_full[L:]
+        # - UNDEFINED, possibly NaN / Inf. Rows are independent in every kernel of the block and ffn.2 reads L rows only.
         # self-attention (model.py:243-247)
         if twin_rows and batch > 1 and sp is None:
             t1 = None if tid is None else tid[:Ls]

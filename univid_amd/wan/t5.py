@@ -118,6 +118,8 @@ class T5Encoder(nn.Module):
         dev = self.token_embedding.weight.device
         ids = ids.to(dev)
         n, d, H = ids.shape[0], self.dim, self.num_heads
+        if n == 0:                    # a tokenizer that emits nothing (not even an end token) for "": the reference slices u[:0] (t5.py:512)
+            return torch.empty(0, d, dtype=BF16, device=dev)
         wf = self._norm_weights()
         x = self.token_embedding.weight.detach()[ids].contiguous()
         span = _round_up(n, 512)      # one bias table per layer serves every prompt length up to text_len

@@ -494,17 +494,18 @@ class WanTI2V:
         if self._progress is None:
             with torch.inference_mode(False):      # normal tensors: written in place by later calls inside or outside inference mode
                 self._progress = (torch.zeros(1, dtype=torch.int64, device=self.device), torch.zeros(1, dtype=torch.int64).pin_memory())
-        self._steps_issued += 1
         dev_ctr, host_ctr = self._progress
-        dev_ctr.fill_(self._steps_issued)
+        dev_ctr.fill_(self._steps_issued + 1)
         host_ctr.copy_(dev_ctr, non_blocking=True)
+        self._steps_issued += 1                    # only once both are enqueued: an exception above must not leave the host a step ahead
 
     def _throttle(self):
         if self._progress is None:
             return
         host_ctr = self._progress[1]
         waited = 0
-        while self._steps_issued - int(host_ctr[0]) >= self.max_steps_in_flight:
+        limit = max(1, int(self.max_steps_in_flight))      # (0 or less would nap forever)
+        while self._steps_issued - int(host_ctr[0]) >= limit:
             time.sleep(1e-3)
             waited += 1
             if waited % 60000 == 0:      # a minute without progress: let a device fault surface as an error instead of napping forever

@@ -597,11 +597,14 @@ class WanVAE_(nn.Module):
             except torch.cuda.OutOfMemoryError:
                 if G == 1:
                     raise
-                logging.warning(f"WanVAE_: out of memory at {G} frames per pass, retrying with {G // 2}")
-                G //= 2
-                self._engine = None          # (its cached frames and rings live in the arena)
-                self._pool = None
-                torch.cuda.empty_cache()
+                retry = G // 2
+            # outside the handler: the exception's traceback (which holds the failed pass's frame - its engine, rows and intermediates, all
+            # arena blocks) is gone, so dropping the engine and the pool really frees the arena before the shorter pass allocates
+            logging.warning(f"WanVAE_: out of memory at {G} frames per pass, retrying with {retry}")
+            G = retry
+            self._engine = None              # (its cached frames and rings live in the arena)
+            self._pool = None
+            torch.cuda.empty_cache()
 
     def encode(self, x, scale):
         """WanVAE_.encode vae2_2.py:783-810: x [1, 3, F, H, W] fp32 -> [1, z, (F-1)//4+1, H/16, W/16]."""
@@ -622,7 +625,9 @@ class WanVAE_(nn.Module):
             out = torch.cat(outs, 0)                                              # [f, h, w, 2z]
             y = eng._pointwise(eng.ops[self.conv1], out)                          # 1x1x1, then chunk(2) -> mu
             f, h, w, _ = y.shape
-            assert (f, h, w) == tuple(mu.shape[2:]), ((f, h, w), mu.shape)
+            if (f, h, w) != tuple(mu.shape[2:]):      # uv_vae_latent_out writes f*h*w*z_dim floats through a raw pointer
+                raise ValueError(f"encoder produced {(f, h, w)} latent positions for a result sized {tuple(mu.shape[2:])} "
+                                 f"(input {tuple(vid.shape)}: H and W must be multiples of 16)")
             _lib.call("uv_vae_latent_out", _lib.ptr(y), y.stride(-2), _lib.ptr(scale[0]), _lib.ptr(scale[1]), _lib.ptr(mu), self.z_dim,
                       f * h * w, _lib.stream_ptr())
             eng.reset()
