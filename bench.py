@@ -23,6 +23,14 @@ import os
 import sys
 import time
 
+# Host scheduling is decided BEFORE the HIP runtime loads (it reads its environment when `import torch` maps libamdhip64): with the runtime's
+# default ("direct dispatch") a HIP-graph replay is submitted by a runtime thread that SPINS while launches are pending - 122-235 ms of CPU per
+# 251 ms step, one busy core per rank (round 5 / 6 measurements) - whatever hipDeviceScheduleBlockingSync says; with AMD_DIRECT_DISPATCH=0 the
+# runtime's command thread blocks instead, and together with uv_host_blocking_sync a whole generation costs 3.4 ms of CPU per step at the same
+# step time. `--host-sync default` leaves both alone. The N ranks torchrun starts run this same file, so each sets it for itself.
+if not any(a == "--host-sync=default" or (a == "--host-sync" and sys.argv[i + 1:i + 2] == ["default"]) for i, a in enumerate(sys.argv)):
+    os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -214,7 +222,7 @@ def default_shape_probe(model, device, cfg, steps=3):
             "finite": bool(torch.isfinite(lat).all().item())}
 
 
-def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=10):
+def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=10, blocking=True):
     """UniVid's OWN entry point on the metric's shape: CrossAttentionFusionPipeline.generate_video_with_bagel_context (reference
     models/model_pipeline.py:2577-2655, what inference.py:311,377 calls) -> Wan22ContextWrapper.generate -> WanTI2V.t2v, with inference.py's
     settings (:52-80: 50 steps, dynamic text weight cosine 1.3 -> 1.0 over int(50 * 0.4) = 20 forwards = the first 10 steps), a stub BAGEL
@@ -266,6 +274,56 @@ def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=
                                  "text weight as data on the fast path (WanModel.set_text_weight / _GraphedPair.apply). host_cpu_ms_per_step here is process CPU "
                                  "time over the WHOLE call, i.e. including the time the host waits for the GPU (the loop keeps <= 4 steps queued and naps; what "
                                  "remains is a ROCm runtime thread that polls while work is pending) - the headline's figure is the enqueue time only")
+        # the same call under the runtime's DEFAULT host scheduling (a waiting host thread spins): what host_cpu_ms_per_step was before round 6
+        if blocking:
+            _lib.host_blocking_sync(False, device)
+            try:
+                _, spin = timed(fusion, closure_steps)
+            finally:
+                _lib.host_blocking_sync(True, device)
+            res["host_sync"] = {"policy": "hipDeviceScheduleBlockingSync + AMD_DIRECT_DISPATCH=%s (bench.py --host-sync blocking, the default; univid_amd.parallel.host_policy / RANK_ENV)" % os.environ.get("AMD_DIRECT_DISPATCH"),
+                                "host_cpu_ms_per_step": res["native"]["host_cpu_ms_per_step"],
+                                "default_policy_host_cpu_ms_per_step": spin["host_cpu_ms_per_step"], "default_policy_ms_per_step": spin["ms_per_step"],
+                                "default_policy_steps": closure_steps}
+        # i2v through the same entry point (inference.py:365-385: image=...): one 704x1280 frame encoded by the VAE (f16x3, random-init), its
+        # latent frame held fixed through the loop (timestep 0 on its tokens, the {0, t} table of the graph runner); 50 steps, encode included
+        try:
+            from univid_amd.wan.vae2_2 import Wan2_2_VAE
+            pipe.vae = Wan2_2_VAE(device=device, seed=0)
+            img = torch.rand(3, 704, 1280, device=device, generator=g) * 2 - 1
+            kw_i = {k: v for k, v in kw.items() if k != "noise"}
+            fusion.generate_video_with_bagel_context("a prompt", image=img, steps=2, seed=7, **kw_i)      # capture of the i2v graph
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lat_i, _ = fusion.generate_video_with_bagel_context("a prompt", image=img, steps=steps, seed=7, **kw_i)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res["i2v"] = {"steps": steps, "seconds": round(dt, 3), "ms_per_step": round(dt / steps * 1e3, 2),
+                          "vs_t2v_ms_per_step": round(dt / steps * 1e3 / res["native"]["ms_per_step"], 4), "finite": bool(torch.isfinite(lat_i).all().item()),
+                          "note": "generate_video_with_bagel_context(text, image=[3,704,1280] tensor): VAE encode of the frame + 50 steps, decode=False; wall clock around the call"}
+            del lat_i
+        except Exception as ex:
+            res["i2v"] = {"error": repr(ex)[:300]}
+        finally:
+            pipe.vae = None
+        # UniVid's DEFAULT clip (inference.py:48-50: 121 frames 704x1280, L = 27 280) through the same entry point: 4 steps after a 2-step capture run
+        try:
+            kw_d = dict(kw, frames=121)
+            kw_d.pop("noise")
+            fusion.generate_video_with_bagel_context("a prompt", steps=2, seed=3, **kw_d)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lat_d, _ = fusion.generate_video_with_bagel_context("a prompt", steps=4, seed=3, **kw_d)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res["default_shape"] = {"workload": "121-frame 704x1280 latent [48,31,44,80], L=27280; 4 steps (all inside the weighted part of the 50-step schedule: every "
+                                                "step refreshes the graph's context K / V buffers)", "steps": 4, "ms_per_step": round(dt / 4 * 1e3, 2),
+                                    "finite": bool(torch.isfinite(lat_d).all().item())}
+            del lat_d
+        except Exception as ex:
+            res["default_shape"] = {"error": repr(ex)[:300]}
+        pipe._runner = None
+        torch.cuda.empty_cache()
         # same first steps through both mechanisms: bit-identical latents (also tests/test_pipeline_path.py)
         lat_a, _ = fusion.generate_video_with_bagel_context("a prompt", steps=closure_steps, **kw)
         lat_a = lat_a.clone()
@@ -563,6 +621,10 @@ def main():
     ap.add_argument("--stress-blocks", type=int, default=0, help="developer runs: the stress-shape probe on a partial stack of this many blocks")
     ap.add_argument("--no-ranker", action="store_true", help="skip the (untimed-region) SigLIP2 ranker measurement (BASELINE config 5)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer DiT blocks (result is NOT the metric)")
+    ap.add_argument("--splitk-strip", action="store_true", help="A/B: ffn.2's leftover rows as one round of 256x256 tiles x split-K 4 (uv_gemm_bf16_nt_ws) instead of "
+                    "the 128x128 ring; opt-in because its rows are not bit-identical to the unsplit accumulation (DESIGN 9, round 6)")
+    ap.add_argument("--host-sync", choices=["blocking", "default"], default="blocking", help="host scheduling policy of this rank's device: blocking = "
+                    "hipDeviceScheduleBlockingSync (a waiting host thread sleeps; what one-rank-per-GPU launches want), default = the runtime's (spins)")
     ap.add_argument("--kernel-times", action="store_true", help="HIP-event timing of every kernel class (adds ~1%% overhead)")
     ap.add_argument("--shape", choices=["A", "B"], default="A", help="A (default, the metric): 49-frame 704x1280 latent [48,13,44,80], "
                     "L = 11 440. B: the literal '49x90x160 latent' stress shape of BASELINE.json's target, [48,49,90,160], L = 176 400 "
@@ -613,7 +675,12 @@ def main():
     cfg = dict(TI2V_5B_CFG)
     if args.layers:
         cfg["num_layers"] = args.layers
+    if args.host_sync == "blocking":
+        _lib.host_blocking_sync(True, device)      # before this rank's first synchronize: N ranks must not spin N cores of one host
     _lib.init()
+    if args.splitk_strip:
+        from univid_amd.wan import model as _wm
+        _wm.SPLITK_STRIP = True
     model = build_model(cfg, device, seed=0)
 
     use_sp = bool(args.sp and world > 1)
@@ -665,16 +732,30 @@ def main():
         for i in range(args.warmup):
             latent = one_step(i, latent)
         barrier()
+        # (three HIP events on the launch stream split THIS rank's timed region into its own steps and the collective - read after the
+        # region, so one --gpus N run answers "compute, collective or host?" per rank without a second run)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         calls0, cpu0 = _lib.CALL_COUNT, time.process_time()
         t0 = time.perf_counter()
+        ev[0].record()
         for i in range(args.warmup, args.warmup + args.steps):
             latent = one_step(i, latent)
         cpu1, calls1 = time.process_time(), _lib.CALL_COUNT     # host work of the steps themselves (launches are asynchronous)
+        ev[1].record()
         if world > 1 and not shared:  # the single collective of the path: final latents to every rank (8.8 MB/GPU)
             gathered = [torch.empty_like(latent) for _ in range(world)]
             dist.all_gather(gathered, latent)
+        ev[2].record()
         barrier()
         dt = time.perf_counter() - t0
+        cpu2 = time.process_time()
+        mine = {"rank": rank, "ms_per_step": round(ev[0].elapsed_time(ev[1]) / args.steps, 3), "allgather_us": round(ev[1].elapsed_time(ev[2]) * 1e3, 1),
+                "host_cpu_ms_per_step_enqueue": round((cpu1 - cpu0) / args.steps * 1e3, 3),
+                "host_cpu_ms_per_step_incl_wait": round((cpu2 - cpu0) / args.steps * 1e3, 3)}
+        per_rank = [mine]
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
         # Live HIP-event timing of the dominant kernel (self-attention) on the launch stream, in a SEPARATE pass behind the timed region
         # (round-3 verdict: the timed steps record nothing the product does not): one more forward pair of the same loop = the 30
         # self-attention launches of a step, each in its real place between the block's other kernels.
@@ -751,6 +832,14 @@ def main():
             "host_cpu_ms_per_step": round((cpu1 - cpu0) / args.steps * 1e3, 3),
             "launches_per_step": round((calls1 - calls0) / args.steps, 1),
             "graph": bool(use_graph),
+            "per_rank": {"ms_per_step_min": min(r["ms_per_step"] for r in per_rank), "ms_per_step_max": max(r["ms_per_step"] for r in per_rank),
+                         "allgather_us_max": max(r["allgather_us"] for r in per_rank),
+                         "host_cpu_ms_per_step_incl_wait_max": max(r["host_cpu_ms_per_step_incl_wait"] for r in per_rank), "ranks": per_rank,
+                         "note": "per rank, HIP events on its launch stream inside the timed region: its own K steps (GPU time), then the one all-gather "
+                                 "(includes waiting for the slowest rank); host CPU = process time of the rank, enqueue only / up to the closing barrier"},
+            "host_sync": args.host_sync,
+            "host_env": {k: os.environ.get(k) for k in ("AMD_DIRECT_DISPATCH", "HSA_ENABLE_IPC_MODE_LEGACY")},
+            "ffn2_strip": "256x256 x split-K 4 (uv_gemm_bf16_nt_ws, --splitk-strip)" if args.splitk_strip else "128x128 ring",
             "host_note": "process CPU time (user + system, all threads of this rank) spent issuing one step's launches, and C-ABI entry-point calls per step",
         }
         if args.kernel_times:
@@ -760,7 +849,7 @@ def main():
             runner = None
             torch.cuda.empty_cache()
             try:
-                out["pipeline_path"] = pipeline_path_probe(model, device, cfg)
+                out["pipeline_path"] = pipeline_path_probe(model, device, cfg, blocking=(args.host_sync == "blocking"))
                 out["pipeline_path"]["vs_headline_ms_per_step"] = round(out["pipeline_path"]["ms_per_step"] / out["ms_per_step"], 4)
             except Exception as ex:      # a side measurement: never fails the bench
                 out["pipeline_path"] = {"error": repr(ex)[:300]}

@@ -27,6 +27,9 @@ const char* uv_build_id(void);             /* digest of the kernel sources the l
 int uv_init(void);                         /* one-time allocations for the CURRENT device; call once per device before use */
 const char* uv_last_error(void);           /* thread-local text of the last failure */
 int uv_device_arch(char* buf, int len);    /* e.g. "gfx950:sramecc+:xnack-" */
+/* Host scheduling policy of the CURRENT device: on = hipDeviceScheduleBlockingSync (a waiting host thread sleeps instead of spinning),
+ * 0 = the runtime's default. Never set implicitly (process-wide policy); one-rank-per-GPU launchers call it once per device. */
+int uv_host_blocking_sync(int on);
 
 /* Developer options: process-wide switches for A/B tools and tests, set EXPLICITLY through these calls - the library never reads the
  * environment. Defaults are what production runs; none of them changes results beyond the f32 summation order noted per key.
@@ -59,6 +62,20 @@ int uv_reset_options(void);
 int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw, const void* bias_bf16, int M, int N, int K,
                     int epilogue, void* out, long ldo, const float* gate, const int32_t* gate_tid, long gate_stride,
                     int tile_cfg, void* stream);
+
+/* uv_gemm_bf16_nt with a caller-owned workspace: the rows a large projection leaves after whole rounds of 256x256 tiles (1 120 of
+ * the 22 880 rows of the CFG pair at 49 x 704 x 1280) run, for K >= 8192 (ffn.2, model.py:214,255), as ONE round of 256x256 tiles x
+ * split-K 4 instead of 128x128 tiles: four f32 partial tiles per output tile, published through the workspace and summed IN SLICE ORDER
+ * by the last-arriving workgroup, which then applies the ordinary epilogue. Deterministic (same bits run to run); the strip's rows differ
+ * from uv_gemm_bf16_nt's by the f32 summation order only (4 partial sums instead of one chain; <= 1 ulp of the epilogue's 16-bit rounding).
+ * workspace: device memory, 256-byte aligned, workspace_bytes >= uv_gemm_splitk_ws_bytes(M, N, K); contents need no initialisation and
+ * are scratch afterwards; launches that share a workspace must be ordered (same stream). NULL / too small: exactly uv_gemm_bf16_nt.
+ * tile_cfg 19 / 20 (tests, tools): the whole problem as split-K 4 / 2 (epilogues 0, 3, 4; workspace 4096 + tiles x split x 256 KiB);
+ * 21 = 19 with one K range per XCD instead of one tile per XCD (placement A/B, same results). */
+int uv_gemm_bf16_nt_ws(const void* A, long lda, const void* W, long ldw, const void* bias_bf16, int M, int N, int K,
+                       int epilogue, void* out, long ldo, const float* gate, const int32_t* gate_tid, long gate_stride,
+                       int tile_cfg, void* workspace, long workspace_bytes, void* stream);
+long uv_gemm_splitk_ws_bytes(int M, int N, int K);   /* 0: tile_cfg 0 has no split-K strip for this shape */
 
 /* uv_gemm_bf16_nt with IEEE fp16 operands, bias and 16-bit outputs (fp32 accumulate): the dtype the reference runs the SigLIP2
  * ranker in (models/BAGEL/eval_understanding.py:172,181,191: fp16 autocast). Same epilogues; tile_cfg must be 0. */

@@ -244,6 +244,94 @@ def test_gemm_schedules_bit_identical(M, N, K):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "row-coalesced RMW epilogue != fragment-wise"
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(1120, 3072, 14336, 4), (1120, 3072, 3072, 4), (1120, 3072, 3072, 2), (300, 512, 1024, 4), (2000, 256, 512, 2)])
+def test_gemm_splitk_strip_deterministic_and_within_one_ulp(M, N, K, sk):
+    """The split-K form of the one-tile-per-workgroup ping-pong kernel (tile_cfg 19 / 20: tiles x split workgroups, f32 partial tiles
+    published through the caller's workspace, summed in slice order by the last arriver, then the ordinary epilogue) - what the ffn.2
+    leftover strip runs as. Not bit-identical to the unsplit accumulation (four f32 partial sums instead of one chain), so: the SAME
+    bits run after run while the chip is busy (arrival order must not matter; a publish / acquire hole would show as a stale tile),
+    >= 99.9 % of the elements identical to the unsplit kernel and none further than one ulp of the epilogue's 16-bit rounding; a
+    poisoned workspace (NaN slabs, garbage counters) changes nothing; the read-modify-write epilogues likewise."""
+    from univid_amd._lib import EPI_BF16, EPI_GATE_RESID_F32, EPI_RESID_F32, UnividHipError
+    g = torch.Generator(device=DEV).manual_seed(M + K + sk)
+    a = (torch.rand(M, K, device=DEV, generator=g) * 2 - 1).to(BF16)
+    w = ((torch.rand(N, K, device=DEV, generator=g) * 2 - 1) * 0.05).to(BF16)
+    bias = (torch.rand(N, device=DEV, generator=g) - 0.5).to(BF16)
+    cfg = {4: 19, 2: 20}[sk]
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    need = 4096 + tiles * sk * 262144
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    ws.view(torch.float32).fill_(float("nan"))                 # slabs AND counters start as garbage
+    ref = torch.zeros(M, N, device=DEV, dtype=BF16)
+    L().gemm_bf16(a, w, bias, ref, EPI_BF16, tile_cfg=7)
+    first = None
+    busy = torch.empty(64 << 20, device=DEV)
+    for rep in range(6):
+        if rep % 2:
+            busy.normal_()                                      # other work in flight: the arrival order of the slices varies
+        out = torch.zeros(M, N, device=DEV, dtype=BF16)
+        L().gemm_bf16(a, w, bias, out, EPI_BF16, tile_cfg=cfg, ws=ws)
+        if first is None:
+            first = out
+        assert torch.equal(out, first), f"rep {rep}: {int((out != first).sum())} elements differ from the first run"
+    same = (first == ref).float().mean().item()
+    d = (first.float() - ref.float()).abs()
+    # (+ an absolute floor: where the partial sums cancel to ~0 the f32 error of the SUMS exceeds the spacing of the tiny RESULT)
+    ulp = bf16_ulp(torch.maximum(ref.float().abs(), first.float().abs())) + 2e-5 * ref.float().abs().max()
+    assert same >= 0.999 and (d <= ulp).all(), (same, float(d.max()))
+    yb = (a.double() @ w.double().t() + bias.double()).to(BF16)
+    assert_bf16_kernel(first, yb, name=f"split-K {sk}")
+    x0 = torch.rand(M, N, device=DEV, generator=g)
+    gate = torch.rand(2, N, device=DEV, generator=g)
+    tid = (torch.arange(M, device=DEV) * 2 // M).to(torch.int32)
+    for epi, kw in ((EPI_RESID_F32, {}), (EPI_GATE_RESID_F32, dict(gate=gate, gate_tid=tid))):
+        xr, xs, xs2 = x0.clone(), x0.clone(), x0.clone()
+        L().gemm_bf16(a, w, bias, xr, epi, tile_cfg=7, **kw)
+        L().gemm_bf16(a, w, bias, xs, epi, tile_cfg=cfg, ws=ws, **kw)
+        L().gemm_bf16(a, w, bias, xs2, epi, tile_cfg=cfg, ws=ws, **kw)
+        assert torch.equal(xs, xs2)
+        scale = gate[tid.long()].abs() if epi == EPI_GATE_RESID_F32 else 1.0
+        dd = (xs - xr).abs()
+        assert (xs == xr).float().mean() >= 0.999 and (dd <= ulp * scale + 1e-6).all(), (epi, float(dd.max()))
+    with pytest.raises(UnividHipError, match="workspace"):
+        L().gemm_bf16(a, w, bias, torch.zeros(M, N, device=DEV, dtype=BF16), EPI_BF16, tile_cfg=cfg, ws=ws[:need - 256])
+
+
+def test_gemm_ffn2_strip_takes_splitk_with_a_workspace():
+    """tile_cfg 0 at the CFG pair's ffn.2 shape (22 880 x 3 072 x 14 336, gated residual): with the workspace uv_gemm_splitk_ws_bytes
+    names, the rows of the whole 256-row rounds are bit-identical to the workspace-free launch and the 1 120 leftover rows are the
+    split-K strip's (= tile_cfg 19 on those rows alone, bit for bit; within one ulp of the 128x128 ring's); without a workspace, or with
+    one that is too small, the call IS the old launch. K = 3 072 projections report no split-K strip."""
+    from univid_amd._lib import EPI_GATE_RESID_F32
+    M, N, K = 22880, 3072, 14336
+    assert L().gemm_splitk_ws_bytes(M, N, 3072) == 0 and L().gemm_splitk_ws_bytes(1024, N, K) == 0
+    need = L().gemm_splitk_ws_bytes(M, N, K)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if cus != 256:
+        pytest.skip(f"the strip geometry below is the 256-CU one ({cus} CUs here)")
+    m_main = 21760
+    assert need == 4096 + 5 * 12 * 4 * 262144
+    g = torch.Generator(device=DEV).manual_seed(11)
+    a = (torch.rand(M, K, device=DEV, generator=g) * 2 - 1).to(BF16)
+    w = ((torch.rand(N, K, device=DEV, generator=g) * 2 - 1) * 0.05).to(BF16)
+    bias = (torch.rand(N, device=DEV, generator=g) - 0.5).to(BF16)
+    x0 = torch.rand(M, N, device=DEV, generator=g)
+    gate = torch.rand(2, N, device=DEV, generator=g)
+    tid = (torch.arange(M, device=DEV) * 2 // M).to(torch.int32)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    kw = dict(gate=gate, gate_tid=tid)
+    plain, with_ws, small_ws, strip = x0.clone(), x0.clone(), x0.clone(), x0[m_main:].clone()
+    L().gemm_bf16(a, w, bias, plain, EPI_GATE_RESID_F32, **kw)
+    L().gemm_bf16(a, w, bias, with_ws, EPI_GATE_RESID_F32, ws=ws, **kw)
+    L().gemm_bf16(a, w, bias, small_ws, EPI_GATE_RESID_F32, ws=ws[:need - 256], **kw)
+    L().gemm_bf16(a[m_main:], w, bias, strip, EPI_GATE_RESID_F32, gate=gate, gate_tid=tid[m_main:], tile_cfg=19, ws=ws)
+    assert torch.equal(small_ws, plain)
+    assert torch.equal(with_ws[:m_main], plain[:m_main])
+    assert torch.equal(with_ws[m_main:], strip)
+    d = (with_ws[m_main:] - plain[m_main:]).abs()
+    assert not torch.equal(with_ws[m_main:], plain[m_main:]) and (d == 0).float().mean() >= 0.999 and float(d.max()) < 0.04
+
+
 def test_gemm_rejects_bad_shapes():
     from univid_amd._lib import EPI_BF16, UnividHipError
     a = torch.zeros(8, 48, dtype=BF16, device=DEV)

@@ -546,7 +546,7 @@ def test_ctypes_signatures_match_the_header_argument_by_argument():
         return {_lib._L: "l", _lib._I: "i", _lib._F: "f"}.get(t, "?" + repr(t))
 
     n = 0
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(uv_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr):
+    for m in re.finditer(r"\b(?:int|long|const char\*)\s+(uv_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr):
         name, args = m.group(1), m.group(2).strip()
         c = [] if args in ("", "void") else [cls_c(a) for a in args.split(",")]
         py = [cls_py(t) for t in _lib.SIGNATURES[name]]

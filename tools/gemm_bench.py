@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--ws", action="store_true", help="pass a split-K workspace (tile_cfg 19 / 20; tile_cfg 0's ffn.2 strip)")
     a = ap.parse_args()
     cfgs = [int(c) for c in a.cfgs.split(",")]
     _lib.init()
@@ -72,12 +73,15 @@ def main():
         else:
             out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
         times = {c: [] for c in cfgs}
+        # split-K configurations (19 / 20) and the automatic choice's split-K strip take a workspace (uv_gemm_bf16_nt_ws)
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        ws = torch.empty(max(4096 + tiles * 4 * 262144 if tiles <= 1024 else 0, _lib.gemm_splitk_ws_bytes(M, N, K), 256), dtype=torch.uint8, device=dev) if a.ws else None
         for r in range(a.rounds + 1):
             for c in cfgs:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.iters):
-                    _lib.gemm_bf16(A, W, bias, out, epi, gate=gate, gate_tid=gate_tid, tile_cfg=c)
+                    _lib.gemm_bf16(A, W, bias, out, epi, gate=gate, gate_tid=gate_tid, tile_cfg=c, ws=ws)
                 e1.record()
                 torch.cuda.synchronize()
                 if r:

@@ -22,10 +22,13 @@ SIGNATURES = {
     "uv_last_error": [],
     "uv_build_id": [],
     "uv_device_arch": [_c.c_char_p, _I],
+    "uv_host_blocking_sync": [_I],
     "uv_set_option": [_I, _I],
     "uv_get_option": [_I, _c.POINTER(_I)],
     "uv_reset_options": [],
     "uv_gemm_bf16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
+    "uv_gemm_bf16_nt_ws": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P, _L, _P],
+    "uv_gemm_splitk_ws_bytes": [_I, _I, _I],
     "uv_gemm_f16_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P],
     "uv_gemm_f32_nt": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _P],
     "uv_gemm_bf16_nt_ssq": [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _L, _I, _P],
@@ -79,7 +82,7 @@ SIGNATURES = {
     "uv_vae_video_in": [_P, _P, _L, _I, _I, _I, _I, _I, _P],
     "uv_vae_video_out": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {"uv_last_error": _c.c_char_p, "uv_build_id": _c.c_char_p}
+_RESTYPE = {"uv_last_error": _c.c_char_p, "uv_build_id": _c.c_char_p, "uv_gemm_splitk_ws_bytes": _L}
 
 OPT_CONV_HALO, OPT_GEMM_GM, OPT_ATTN_CUT = range(3)      # include/univid_hip.h: UV_OPT_*
 EPI_BF16, EPI_GELU_BF16, EPI_F32_FROM_BF16, EPI_RESID_F32, EPI_GATE_RESID_F32, EPI_BF16_T = range(6)
@@ -245,13 +248,40 @@ def _chk(t, dtype, name):
         raise UnividHipError(f"{name}: innermost dimension must be contiguous")
 
 
-def gemm_bf16(a, w, bias, out, epi, M=None, gate=None, gate_tid=None, tile_cfg=0):
-    """a [M,K] bf16, w [N,K] bf16, bias bf16 [N] | None; out per epilogue (see include/univid_hip.h)."""
+def host_blocking_sync(on=True, device=None):
+    """uv_host_blocking_sync for `device` (default: the current one): a host thread waiting in synchronize sleeps instead of spinning.
+    Process-wide policy: the APPLICATION decides (bench.py's ranks and univid_amd.parallel's workers call it; a library import never does)."""
+    dev = torch.device("cuda" if device is None else device)
+    idx = torch.cuda.current_device() if dev.index is None else dev.index
+    lib = load()
+    with torch.cuda.device(idx):
+        if lib.uv_host_blocking_sync(1 if on else 0) != 0:
+            raise UnividHipError(lib.uv_last_error().decode())
+
+
+def gemm_splitk_ws_bytes(M, N, K, device=None):
+    """Bytes of workspace with which gemm_bf16(..., ws=) runs the leftover-row strip of an [M, K] x [N, K]^T projection as one round of
+    split-K workgroups (0: this shape has no such strip). The answer depends on the device's CU count."""
+    dev = torch.device("cuda" if device is None else device)
+    idx = torch.cuda.current_device() if dev.index is None else dev.index
+    lib = init(idx)
+    with torch.cuda.device(idx):
+        return int(lib.uv_gemm_splitk_ws_bytes(int(M), int(N), int(K)))
+
+
+def gemm_bf16(a, w, bias, out, epi, M=None, gate=None, gate_tid=None, tile_cfg=0, ws=None):
+    """a [M,K] bf16, w [N,K] bf16, bias bf16 [N] | None; out per epilogue (see include/univid_hip.h).
+    ws: uint8 scratch tensor of >= gemm_splitk_ws_bytes(M, N, K) bytes (uv_gemm_bf16_nt_ws), or None."""
     f16 = a.dtype == torch.float16      # IEEE fp16 operands (SigLIP2 ranker): same kernels, fp16 MFMA / conversions
     _chk(a, torch.float16 if f16 else torch.bfloat16, "gemm_bf16.a")
     _chk(w, a.dtype, "gemm_bf16.w")
     M = a.shape[0] if M is None else M
     N, K = w.shape
+    if ws is not None and not f16:
+        _chk(ws, torch.uint8, "gemm_bf16.ws")
+        call("uv_gemm_bf16_nt_ws", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), M, N, K, epi, ptr(out), out.stride(0),
+             ptr(gate), ptr(gate_tid), 0 if gate is None else gate.stride(0), tile_cfg, ptr(ws), ws.numel(), stream_ptr(), flops=2 * M * N * K)
+        return out
     call("uv_gemm_f16_nt" if f16 else "uv_gemm_bf16_nt", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), M, N, K, epi, ptr(out), out.stride(0),
          ptr(gate), ptr(gate_tid), 0 if gate is None else gate.stride(0), tile_cfg, stream_ptr(), flops=2 * M * N * K)
     return out

@@ -67,6 +67,20 @@ extern "C" int uv_init(void) {
     return 0;
 }
 
+// Host scheduling policy of the CURRENT device: hipDeviceScheduleBlockingSync (the host thread sleeps on an interrupt inside
+// hipStreamSynchronize / hipDeviceSynchronize / hipEventSynchronize instead of spinning on the completion signal) or the runtime's default.
+// Process-wide policy, so never set implicitly: the application calls it once per device, before its first synchronize - bench.py's ranks
+// and univid_amd.parallel's workers do, because eight ranks spinning on one host is the scaling risk SURVEY 8(e) names.
+extern "C" int uv_host_blocking_sync(int on) {
+    const hipError_t e = hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        uv_set_error("uv_host_blocking_sync: hipSetDeviceFlags failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
+}
+
 // Device arch string of the current device, for the loader's "is this gfx950" check.
 extern "C" int uv_device_arch(char* buf, int len) {
     hipDeviceProp_t prop;

@@ -12,11 +12,30 @@ static int num_cus() { return uv_num_cus(); }
 template <bool F16>
 static int launch_by_cfg(const GemmArgs& a, int epilogue, int tile_cfg, hipStream_t s);
 
+// The caller's split-K workspace (uv_gemm_bf16_nt_ws), or nothing.
+struct GemmWs {
+    void* p = nullptr;
+    long bytes = 0;
+};
+
+// Does the leftover strip `at` run as ONE round of 256x256 tiles x split-K 4? Only where that measured faster than the 128x128 ring
+// (tools/gemm_bench.py, round 6): the long-K strips (ffn.2: K = 14 336, 144 -> 121 us in isolation); at K = 3 072 a slice is 12 K tiles
+// and the publish + combine (~40 us: 63 MB of partial tiles out and back in) costs more than the whole ring launch (63 against 35 us). Needs the residual / bf16 epilogues, whole slices, at most one round of workgroups, and a
+// caller-provided workspace.
+template <bool F16>
+static bool strip_takes_splitk(const GemmArgs& at, int epilogue, const GemmWs& ws) {
+    if (F16 || !ws.p) return false;
+    if (epilogue != UV_EPI_BF16 && epilogue != UV_EPI_RESID_F32 && epilogue != UV_EPI_GATE_RESID_F32) return false;
+    if (at.K < 8192 || at.K % 512 != 0 || at.N % 256 != 0) return false;
+    const long tiles = (long)((at.M + 255) / 256) * (at.N / 256);
+    return tiles * 4 <= num_cus() && ws.bytes >= splitk_ws_bytes(at.M, at.N, 4) && ((uintptr_t)ws.p & 255) == 0;
+}
+
 // Rows that fill whole rounds of 256x256 tiles go to the big-tile kernel; the leftover rows (which would otherwise cost a
 // whole extra round on a fraction of the CUs) run as 128x128 tiles. Same arithmetic per element either way.
 // m_main > 0 names the split point explicitly (a multiple of 256).
 template <bool F16>
-static int launch_m_split(const GemmArgs& a, int epilogue, int main_cfg, hipStream_t s, long m_main = 0) {
+static int launch_m_split(const GemmArgs& a, int epilogue, int main_cfg, hipStream_t s, long m_main = 0, const GemmWs& ws = GemmWs()) {
     const long tiles_n = (a.N + 255) / 256, tiles_m = (a.M + 255) / 256;
     if (m_main <= 0) {
         const long rounds = tiles_m * tiles_n / num_cus();
@@ -34,13 +53,16 @@ static int launch_m_split(const GemmArgs& a, int epilogue, int main_cfg, hipStre
     else at.out = (float*)a.out + m_main * a.ldo;
     if (a.ssq) at.ssq = a.ssq + m_main * a.ld_ssq;
     const int rc = launch_by_cfg<F16>(am, epilogue, main_cfg, s);
-    return rc ? rc : launch_by_cfg<F16>(at, epilogue, 12, s);
+    if (rc) return rc;
+    if constexpr (!F16)
+        if (strip_takes_splitk<F16>(at, epilogue, ws)) return launch_8ph_splitk<4, false>(at, epilogue, s, ws.p, ws.bytes);
+    return launch_by_cfg<F16>(at, epilogue, 12, s);
 }
 
 template <bool F16>
 static int gemm_entry(const void* A, long lda, const void* W, long ldw, const void* bias_bf16, int M, int N, int K, int epilogue,
                       void* out, long ldo, const float* gate, const int32_t* gate_tid, long gate_stride, int tile_cfg, void* stream,
-                      float* ssq = nullptr, long ld_ssq = 0) {
+                      float* ssq = nullptr, long ld_ssq = 0, const GemmWs& ws = GemmWs()) {
     UV_CHECK_ARG(A && W && out, "uv_gemm_bf16_nt: null pointer");
     UV_CHECK_ARG(M > 0 && N > 0 && K > 0, "uv_gemm_bf16_nt: bad shape M=%d N=%d K=%d", M, N, K);
     UV_CHECK_ARG(K % UV_BK == 0, "uv_gemm_bf16_nt: K=%d must be a multiple of %d", K, UV_BK);
@@ -57,6 +79,7 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
     a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.gate_stride = gate_stride;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
     a.ssq = ssq; a.ld_ssq = ld_ssq;
+    a.ws_slab = nullptr; a.ws_cnt = nullptr; a.gm = 0;
     if (epilogue == UV_EPI_BF16_SSQ)
         UV_CHECK_ARG(ssq && N % 32 == 0 && ld_ssq >= N / 32 && ldo % 8 == 0, "uv_gemm_bf16_nt_ssq: needs N %% 32 == 0, ld_ssq >= N / 32, ldo %% 8 == 0 (N=%d ld_ssq=%ld ldo=%ld)", N, ld_ssq, ldo);
     a.zeros = uv_zero_page();
@@ -77,7 +100,12 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
             if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) return launch_m_split<F16>(a, epilogue, 7, s);
             return launch_by_cfg<F16>(a, epilogue, 7, s);
         }
-        return launch_m_split<F16>(a, epilogue, 17, s, m_main);
+        return launch_m_split<F16>(a, epilogue, 17, s, m_main, ws);
+    }
+    if constexpr (!F16) {      // tests / tools: the WHOLE problem as split-K 4 (19) or 2 (20) on the one-tile-per-workgroup ping-pong kernel
+        if (tile_cfg == 19) return launch_8ph_splitk<4, false>(a, epilogue, s, ws.p, ws.bytes);
+        if (tile_cfg == 20) return launch_8ph_splitk<2, false>(a, epilogue, s, ws.p, ws.bytes);
+        if (tile_cfg == 21) { a.gm = 1; return launch_8ph_splitk<4, false>(a, epilogue, s, ws.p, ws.bytes); }      // A/B: one K range per XCD
     }
     if (tile_cfg == 8) return launch_m_split<F16>(a, epilogue, 7, s);
     if (tile_cfg == 9) return launch_m_split<F16>(a, epilogue, 5, s);
@@ -90,6 +118,32 @@ extern "C" int uv_gemm_bf16_nt(const void* A, long lda, const void* W, long ldw,
                                const float* gate, const int32_t* gate_tid, long gate_stride,
                                int tile_cfg, void* stream) {
     return gemm_entry<false>(A, lda, W, ldw, bias_bf16, M, N, K, epilogue, out, ldo, gate, gate_tid, gate_stride, tile_cfg, stream);
+}
+
+// uv_gemm_bf16_nt with a caller-owned WORKSPACE (see include/univid_hip.h): lets the leftover-row strip of a long-K projection run as one
+// round of split-K workgroups. Without a (large enough) workspace it IS uv_gemm_bf16_nt.
+extern "C" int uv_gemm_bf16_nt_ws(const void* A, long lda, const void* W, long ldw, const void* bias_bf16,
+                                  int M, int N, int K, int epilogue, void* out, long ldo,
+                                  const float* gate, const int32_t* gate_tid, long gate_stride,
+                                  int tile_cfg, void* workspace, long workspace_bytes, void* stream) {
+    UV_CHECK_ARG(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "uv_gemm_bf16_nt_ws: bad workspace");
+    GemmWs ws;
+    ws.p = workspace; ws.bytes = workspace_bytes;
+    return gemm_entry<false>(A, lda, W, ldw, bias_bf16, M, N, K, epilogue, out, ldo, gate, gate_tid, gate_stride, tile_cfg, stream, nullptr, 0, ws);
+}
+
+// Bytes of workspace with which uv_gemm_bf16_nt_ws(M, N, K, tile_cfg 0) takes its split-K strip (0: this shape has none): the
+// largest strip tile_cfg 0 can cut from M rows is one round of 256x256 tiles less one row of tiles.
+extern "C" long uv_gemm_splitk_ws_bytes(int M, int N, int K) {
+    if (M < 2048 || N < 1024 || N % 256 != 0 || K < 8192 || K % 512 != 0) return 0;
+    const long tn = N / 256, tm_full = M / 256;
+    const long tiles = (long)((M + 255) / 256) * tn;
+    const long rounds = tiles / num_cus(), rest = tiles - rounds * num_cus();
+    long m_main = tm_full * 256;
+    if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) m_main = rounds * num_cus() / tn * 256;
+    if (m_main / 256 * tn < 2L * num_cus() || m_main >= M) return 0;
+    const long strip_tiles = ((M - m_main) + 255) / 256 * tn;
+    return strip_tiles * 4 <= num_cus() ? splitk_ws_bytes((int)(M - m_main), N, 4) : 0;
 }
 
 // UV_EPI_BF16 plus the output's sums of squares per aligned 32-column group (see include/univid_hip.h): the q projection whose RMSNorm is applied

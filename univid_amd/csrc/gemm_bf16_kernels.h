@@ -55,6 +55,8 @@ struct GemmArgs {
     int gm;                   // persistent kernel: height (in tiles) of the column groups the tile walk is made of
     float* ssq;               // UV_EPI_BF16_SSQ: [M, ld_ssq] f32 partial sums of squares, one per 32-column group
     long ld_ssq;
+    float* ws_slab;           // split-K launch (gemm_bf16_8ph_kernel<.., SK > 1>): f32 partial tiles [tile][slice][32 fragments][512 threads][4]
+    int* ws_cnt;              //   and one arrival counter per output tile (zeroed by a memset node in front of every launch)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -570,10 +572,26 @@ __device__ __forceinline__ void epi_rmw_rows_lds(const GemmArgs& p, char* smem, 
 // phases pairwise - 32 MFMAs per cluster, half as many barriers and cluster ramps per MFMA: +2-4 % measured.
 // Needs N % 256 == 0 rows of W to exist (clamped like A otherwise) and an even K/64 >= 4.
 #define UV_SB() __builtin_amdgcn_s_barrier()
+#ifndef UV_REBAL
+#define UV_REBAL 1   // VAR 5: W[0] of K tile t+1 is staged in phase A of K tile t (into the other buffer, beside A[1]) instead of as W[0] of t+2 in phase B of t-1:
+                     // 4 + 4 LDS-DMA pieces per phase instead of 2 + 6. Same arithmetic, bit-identical
+#endif
 #define UV_SCHED() __builtin_amdgcn_sched_barrier(0)
 
-template <int EPI, int VAR = 0, bool F16 = false>
+// SK > 1 (VAR 5 only): SPLIT-K form for the leftover-row strips of the long-K projections (ffn.2: 1 120 rows x 3 072 columns x K 14 336 =
+// 60 tiles, a quarter of a round). The grid is tiles x SK workgroups - ONE round of the chip - and workgroup (tile, slice) runs the
+// same ping-pong K loop over K / SK. Placement (speed only, never correctness): the SK slices of a tile run on ONE XCD, so the last
+// arriver reads the other slabs from its own L2 (measured 120.8 us on the ffn.2 strip; with one K range per XCD - operand panels fetched
+// once per XCD, slabs crossing the fabric - 134.2; the 128x128 ring 144.1 in the same run: the 63 MB of partial tiles, not the 120 MB of
+// operands, are what a one-round split-K launch waits for). Every slice leaves its f32 partial tile in a slab (fragment-major,
+// 1 KiB per wave-instruction), publishes it (vmcnt(0) -> barrier -> one agent-scope release fence -> relaxed ticket on the tile's
+// counter) and ends; the workgroup that draws the last ticket acquires once, sums the SK slabs IN SLICE ORDER ((s0 + s1) + s2) + s3 -
+// its own included, read back from the slab, so the result does not depend on who arrives last - and runs the ordinary epilogue.
+// Deterministic run to run; NOT bit-identical to the unsplit accumulation (four f32 partial sums instead of one chain: <= 1 ulp of
+// the 16-bit rounding in the epilogue on a tiny fraction of the elements).
+template <int EPI, int VAR = 0, bool F16 = false, int SK = 1>
 __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
+    static_assert(SK == 1 || (VAR == 5 && (8 % SK) == 0), "split-K: VAR 5, SK in {2, 4, 8}");
     constexpr bool TRANS = (EPI == UV_EPI_BF16_T);
     constexpr int HALF = 16384;      // one half-tile: 128 rows x 128 B
     constexpr int BUF = 4 * HALF;    // A[0] A[1] W[0] W[1]
@@ -586,9 +604,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
 
     const int nblk = p.tiles_m * p.tiles_n;
     int bid = blockIdx.x;
-    {
+    int slice = 0;
+    if constexpr (SK == 1) {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    } else {
+        const int xcd = bid & 7, idx = bid >> 3, per = gridDim.x >> 3;
+        if (p.gm == 0) {        // the SK slices of a tile on ONE XCD: per = ceil(nblk * SK / 8) (tile, slice) units per XCD
+            const int u = xcd * per + idx;
+            slice = u % SK;
+            bid = u / SK;
+        } else {                // A/B (tile_cfg 21): XCD x takes slice x % SK of the tiles of part x / SK; per = ceil(nblk / (8 / SK)) tiles per XCD
+            slice = xcd % SK;
+            bid = (xcd / SK) * per + idx;
+        }
+        if (bid >= nblk) return;
     }
     constexpr int GM = 4;
     const int group_sz = GM * p.tiles_n;
@@ -597,6 +627,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     const int gm = min(GM, p.tiles_m - first_m);
     const int in_group = bid - group * group_sz;
     const int m0 = (first_m + in_group % gm) * 256, n0 = (in_group / gm) * 256;
+    const int kbeg = SK == 1 ? 0 : slice * (p.K / SK);                       // this slice's first k
 
     // staging sources: half-tile h, wave-instruction i covers rows (i*8 + wave)*8 + srow of the half-tile
     const int srow = lane >> 3, pchunk = lane & 7;
@@ -608,11 +639,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
         for (int i = 0; i < 2; ++i) {
             const int row = (i * 8 + wave) * 8 + srow;
             const int c = pchunk ^ ((row >> 1) & 7);
-            a_src[h][i] = p.A + (long)min(m0 + h * 128 + row, p.M - 1) * p.lda + c * 8;
-            w_src[h][i] = p.W + (long)min(n0 + h * 128 + row, p.N - 1) * p.ldw + c * 8;
+            a_src[h][i] = p.A + (long)min(m0 + h * 128 + row, p.M - 1) * p.lda + c * 8 + kbeg;
+            w_src[h][i] = p.W + (long)min(n0 + h * 128 + row, p.N - 1) * p.ldw + c * 8 + kbeg;
         }
     char* const my_dst = smem + wave * 1024;
-    const int nk = p.K / UV_BK;
+    const int nk = p.K / SK / UV_BK;
 #define UV_STAGE(SRC, KT, DSTOFF)                                         \
     {                                                                     \
         const bf16_t* g0_ = SRC[0] + (long)(KT) * UV_BK;                  \
@@ -685,16 +716,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     UV_SB(); UV_SCHED();                                                                          \
     UV_MFMA_Q(1, 0, w0) UV_SCHED(); UV_SB();
 // VAR 5: two phases of 32 MFMAs per K tile instead of four of 16 (half as many barriers and cluster ramps per MFMA):
-//     phase A   LDS reads W[0] W[1] A[0] (16)   MFMA (A0,W0) (A0,W1)   DMA A[1] of K tile t+1
-//     phase B   LDS reads A[1] (8)              MFMA (A1,W1) (A1,W0)   DMA W[0] W[1] A[0] of K tile t+2
-// Every half-tile is restaged one phase after its only read phase, so the reads are retired (lgkmcnt(0)) BEFORE the first
-// barrier; each phase waits vmcnt(8) after its own DMA issue, which retires the half-tiles read in the NEXT phase.
-// UV_KTILE5X names the K-tile indices of its two staging groups separately (K1: the A[1] half staged in phase A, K2: W[0] W[1]
+//     phase A   LDS reads W[0] W[1] A[0] (16)   MFMA (A0,W0) (A0,W1)   DMA W[0] A[1] of K tile t+1 (other buffer)
+//     phase B   LDS reads A[1] (8)              MFMA (A1,W1) (A1,W0)   DMA W[1] A[0] of K tile t+2 (this buffer)
+// (4 + 4 LDS-DMA pieces per wave; UV_REBAL 0 = the schedule of rounds 2-5 with 2 + 6: A[1] of t+1 | W[0] W[1] A[0] of t+2.)
+// A half-tile is restaged only after BOTH wave groups have retired their reads of it: the second group runs one barrier behind the
+// first, so a piece staged in front of a phase's first barrier may only overwrite what was last read a whole phase earlier - W[0] of the
+// OTHER buffer (read in phase A of the previous K tile) qualifies in phase A, W[0] of this buffer does not. Each phase waits on a counted
+// vmcnt after its own DMA issue (A: 8, B: 6), which retires exactly the half-tiles the NEXT phase reads.
+// UV_KTILE5X names the K-tile indices of its two staging groups separately (K1: the W[0] A[1] halves staged in phase A, K2: W[1]
 // A[0] staged in phase B): the persistent kernel stages the NEXT output tile's first K tiles through the same code at a tile's end.
 #define UV_KTILE5(T, B, O, ST1, ST2) UV_KTILE5X((T) + 1, (T) + 2, B, O, ST1, ST2)
 #define UV_KTILE5X(K1, K2, B, O, ST1, ST2)                                                        \
     UV_RD_W(B, 0, w0) UV_RD_W(B, 1, w1) UV_RD_A(B, 0)                                             \
     if (ST1) {                                                                                    \
+        if (UV_REBAL) UV_STAGE(w_src[0], K1, (O) * BUF + 2 * HALF)                                \
         UV_STAGE(a_src[1], K1, (O) * BUF + HALF)                                                  \
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
     } else {                                                                                      \
@@ -706,10 +741,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(0); UV_SCHED(); UV_SB();                                           \
     UV_RD_A(B, 1)                                                                                 \
     if (ST2) {                                                                                    \
-        UV_STAGE(w_src[0], K2, (B) * BUF + 2 * HALF)                                              \
+        if (!UV_REBAL) UV_STAGE(w_src[0], K2, (B) * BUF + 2 * HALF)                               \
         UV_STAGE(w_src[1], K2, (B) * BUF + 3 * HALF)                                              \
         UV_STAGE(a_src[0], K2, (B) * BUF)                                                         \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
+        if (UV_REBAL) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                            \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                     \
     } else if (ST1) {                                                                             \
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                          \
     } else {                                                                                      \
@@ -725,8 +761,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     if constexpr (VAR == 5) {
         // prologue: W0 W1 A0 A1 of K tile 0, W0 W1 A0 of K tile 1; vmcnt(8) = W0 W1 A0 of K tile 0 landed
         UV_STAGE(w_src[0], 0, 2 * HALF) UV_STAGE(w_src[1], 0, 3 * HALF) UV_STAGE(a_src[0], 0, 0) UV_STAGE(a_src[1], 0, HALF)
-        UV_STAGE(w_src[0], 1, BUF + 2 * HALF) UV_STAGE(w_src[1], 1, BUF + 3 * HALF) UV_STAGE(a_src[0], 1, BUF)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (!UV_REBAL) UV_STAGE(w_src[0], 1, BUF + 2 * HALF)
+        UV_STAGE(w_src[1], 1, BUF + 3 * HALF) UV_STAGE(a_src[0], 1, BUF)
+        if (UV_REBAL) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
         // prologue: K tile 0 (W0 A0 W1 A1) and W0 A0 W1 of K tile 1; vmcnt(6) = K tile 0 landed
         UV_STAGE(w_src[0], 0, 2 * HALF) UV_STAGE(a_src[0], 0, 0) UV_STAGE(w_src[1], 0, 3 * HALF) UV_STAGE(a_src[1], 0, HALF)
@@ -744,6 +782,68 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmArgs p) {
     UV_KTILE(t, 0, 1, true, false)
     UV_KTILE(t + 1, 1, 0, false, false)
     if (wr == 0) UV_SB();
+
+    if constexpr (SK > 1) {
+        // ---- publish this slice's partial tile: slab[tile][slice][f][tid] (f = fragment index in the accumulator array's own order).
+        // Buffer addressing (one descriptor for the tile's SK slabs, the thread's 16-byte column as the VGPR offset, slab / fragment as
+        // the scalar offset): flat addressing would hold one 64-bit address pair per store / load - 300 spilled registers in hipcc's build
+        f32x4* const accf = &acc[0][0][0][0];
+        const auto slabs = __builtin_amdgcn_make_buffer_rsrc(p.ws_slab + (long)bid * SK * 65536, 0, SK * 262144, 0x00020000);
+        const int voff = tid * 16;
+        // fragment f = ((hn * 2 + hm) * 2 + i) * 4 + j covers rows m0 + 128 hm + 64 wr + 16 j ..+15: fragments wholly below the matrix (the
+        // last row tile of a strip: 96 of 256 rows at 1 120) are neither published nor summed
+        const int row_lim = p.M - m0 - wr * 64;      // fragment (hm, j) is live iff 128 hm + 16 j < row_lim (wave-uniform)
+#pragma unroll
+        for (int f = 0; f < 32; ++f)
+            if (((f >> 3) & 1) * 128 + (f & 3) * 16 < row_lim)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, accf[f]), slabs, voff, slice * 262144 + f * 8192, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // every wave's slab stores are complete (and its K-loop LDS reads retired)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (keep: the fence's own wait can be dropped by the compiler)
+            const int ticket = __hip_atomic_fetch_add(p.ws_cnt + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == SK - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *(volatile int*)smem = ticket;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int ticket = __builtin_amdgcn_readfirstlane(*(volatile int*)smem);
+        if (ticket != SK - 1) return;
+        // ---- last arriver: the tile = the slabs summed in slice order, G fragments x SK slabs in flight per thread
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // (the epilogues below reuse smem: everyone has read the ticket)
+        constexpr int G = 4;
+#pragma unroll
+        for (int f0 = 0; f0 < 32; f0 += G) {
+            f32x4 v[G][SK];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int sl = 0; sl < SK; ++sl) {
+                    v[g][sl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if ((((f0 + g) >> 3) & 1) * 128 + ((f0 + g) & 3) * 16 < row_lim)
+                        v[g][sl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(slabs, voff, sl * 262144 + (f0 + g) * 8192, 0));
+                }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                f32x4 sum = v[g][0];
+#pragma unroll
+                for (int sl = 1; sl < SK; ++sl)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sum[e] = __fadd_rn(sum[e], v[g][sl][e]);
+                // the sum must EXIST here: left alone, hipcc sinks all 32 x (SK - 1) x 4 additions behind the last load (their only use is
+                // the epilogue) and keeps 32 x SK loaded fragments alive meanwhile - 280 spilled registers
+                asm volatile("" : "+v"(sum));
+                accf[f0 + g] = sum;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 
     if constexpr ((EPI == UV_EPI_RESID_F32 || EPI == UV_EPI_GATE_RESID_F32) && VAR != 0) {
         // every wave has left the K loop's last LDS reads behind (the loop ends on a barrier both groups take)
@@ -872,8 +972,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_persist_kernel(GemmArgs p) 
         if (fresh) {
             // prologue: W0 W1 A0 A1 of K tile 0, W0 W1 A0 of K tile 1; vmcnt(8) = W0 W1 A0 of K tile 0 landed
             UV_STAGE(w_src[0], 0, 2 * HALF) UV_STAGE(w_src[1], 0, 3 * HALF) UV_STAGE(a_src[0], 0, 0) UV_STAGE(a_src[1], 0, HALF)
-            UV_STAGE(w_src[0], 1, BUF + 2 * HALF) UV_STAGE(w_src[1], 1, BUF + 3 * HALF) UV_STAGE(a_src[0], 1, BUF)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (!UV_REBAL) UV_STAGE(w_src[0], 1, BUF + 2 * HALF)
+            UV_STAGE(w_src[1], 1, BUF + 3 * HALF) UV_STAGE(a_src[0], 1, BUF)
+            if (UV_REBAL) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             UV_SB();
         }
         fresh = RMW;
@@ -906,8 +1008,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_persist_kernel(GemmArgs p) 
             // a branch makes hipcc shuttle all 128 accumulators through copies and spill): staged meanwhile are A[1] of K tile
             // nk-1 (old pointer) and then K tiles 0 and 1 of the next output tile. The workgroup's last tile "prefetches" its own
             // first K tiles again (dA = dW = 0: 128 KiB of harmless loads, drained before the workgroup ends).
-            move_ptrs(w_src[0], dW); move_ptrs(w_src[1], dW); move_ptrs(a_src[0], dA);
+            if (!UV_REBAL) move_ptrs(w_src[0], dW);
+            move_ptrs(w_src[1], dW); move_ptrs(a_src[0], dA);
             UV_KTILE5X(nk - 1, 0, 0, 1, true, true)
+            if (UV_REBAL) move_ptrs(w_src[0], dW);      // (W[0] travels with A[1]: phase A's pieces belong to the K tile after this one)
             move_ptrs(a_src[1], dA);
             UV_KTILE5X(0, 1, 1, 0, true, true)
         } else {
@@ -989,6 +1093,49 @@ static int launch_8ph(const GemmArgs& a0, int epi, hipStream_t stream) {
     }
 #undef UV_LAUNCH8
     UV_CHECK_LAUNCH("uv_gemm_bf16_nt");
+    return 0;
+}
+
+// Split-K launch of the one-tile-per-workgroup ping-pong kernel (see gemm_bf16_8ph_kernel<.., SK>): workspace = [4 KiB of tile counters]
+// [tiles x SK slabs of 256 KiB]. The counters are zeroed by a memset node on the stream in front of EVERY launch (a capture records it).
+static inline long splitk_ws_bytes(int M, int N, int sk) { return 4096 + (long)((M + 255) / 256) * ((N + 255) / 256) * sk * 262144L; }
+
+template <int SK, bool F16 = false>
+static int launch_8ph_splitk(const GemmArgs& a0, int epi, hipStream_t stream, void* ws, long ws_bytes) {
+    GemmArgs a = a0;
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 255) / 256;
+    const int tiles = a.tiles_m * a.tiles_n;
+    UV_CHECK_ARG(a.K % (SK * 128) == 0 && a.K / SK >= 256, "uv_gemm_bf16_nt_ws: split-K %d needs K %% %d == 0 and K / %d >= 256 (K=%d)", SK, SK * 128, SK, a.K);
+    UV_CHECK_ARG(tiles <= 1024, "uv_gemm_bf16_nt_ws: split-K serves leftover strips (at most 1024 tiles; %d here)", tiles);
+    UV_CHECK_ARG(ws && ((uintptr_t)ws & 255) == 0 && ws_bytes >= splitk_ws_bytes(a.M, a.N, SK),
+                 "uv_gemm_bf16_nt_ws: workspace of %ld bytes (256-byte aligned) needed, %ld given", splitk_ws_bytes(a.M, a.N, SK), ws_bytes);
+    a.ws_cnt = (int*)ws;
+    a.ws_slab = (float*)((char*)ws + 4096);
+    if (hipMemsetAsync(a.ws_cnt, 0, (size_t)tiles * sizeof(int), stream) != hipSuccess) {
+        uv_set_error("uv_gemm_bf16_nt_ws: hipMemsetAsync of the tile counters failed");
+        return -1;
+    }
+    const int per = a.gm == 0 ? (tiles * SK + 7) / 8 : (tiles + 8 / SK - 1) / (8 / SK);
+    const dim3 grid(8 * per), block(512);
+    const size_t lds = 128 * 1024;
+#define UV_LAUNCH8S(E)                                                                             \
+    case E: {                                                                                      \
+        auto kern = gemm_bf16_8ph_kernel<E, 5, F16, SK>;                                           \
+        UV_ONCE_PER_DEVICE(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                     \
+        break;                                                                                     \
+    }
+    switch (epi) {
+        UV_LAUNCH8S(UV_EPI_BF16)
+        UV_LAUNCH8S(UV_EPI_RESID_F32)
+        UV_LAUNCH8S(UV_EPI_GATE_RESID_F32)
+        default:
+            uv_set_error("uv_gemm_bf16_nt_ws: the split-K strip is built for the bf16 and the residual epilogues (0, 3, 4), not %d", epi);
+            return -1;
+    }
+#undef UV_LAUNCH8S
+    UV_CHECK_LAUNCH("uv_gemm_bf16_nt_ws");
     return 0;
 }
 

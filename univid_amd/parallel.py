@@ -14,6 +14,30 @@ import torch
 import torch.distributed as dist
 
 
+_blocking_set = set()
+
+# What a one-rank-per-GPU launcher exports BEFORE its ranks import torch (the HIP runtime reads its environment when it is loaded):
+#   AMD_DIRECT_DISPATCH=0        HIP-graph replays are submitted by the runtime's command thread, which blocks while launches are pending; under
+#                                the default (direct dispatch) a runtime thread spins instead - one busy core per rank (bench.py: 122 ms of CPU
+#                                per 251 ms step, against 3.4 ms with this and host_policy() below; same step time)
+#   HSA_ENABLE_IPC_MODE_LEGACY=0 dmabuf IPC for RCCL on this pool's driver
+RANK_ENV = {"AMD_DIRECT_DISPATCH": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+
+
+def host_policy(device, blocking_sync=True):
+    """One rank per GPU on ONE host: a rank that waits for its GPU must SLEEP (hipDeviceScheduleBlockingSync), not spin - with the runtime's
+    default policy every waiting rank keeps a core busy (round 5: 209-235 ms of process CPU per 252 ms step), which at 8 ranks is the host
+    contention SURVEY 8(e) names as the scaling risk. Idempotent per device; called by denoise_batch for multi-rank jobs and by bench.py's
+    ranks; a single-process user calls it (or not) as it sees fit - it is process-wide policy, so importing the package never sets it."""
+    device = torch.device(device)
+    if device.type != "cuda" or (device.index, blocking_sync) in _blocking_set:
+        return
+    from . import _lib
+    _lib.host_blocking_sync(blocking_sync, device)
+    _blocking_set.discard((device.index, not blocking_sync))
+    _blocking_set.add((device.index, blocking_sync))
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -77,6 +101,8 @@ def denoise_batch(pipe, noises: Sequence[torch.Tensor], contexts, contexts_null,
     rank, ws = world()
     n = len(noises)
     lo, hi = shard_range(n, rank, ws)
+    if ws > 1 and len(noises) and noises[0].is_cuda:
+        host_policy(noises[0].device)
 
     def one(i):
         if wrapper is not None and wrapper.config.use_dynamic_text_weight:

@@ -345,8 +345,12 @@ class WanAttentionBlock(nn.Module):
         _lib.layernorm_mod(x, h, L, C, self.eps, mode=1, tab=tab, shift_off=3 * C, scale_off=4 * C, tid=tid)
         mid = torch.empty(Lf, self.ffn_dim, dtype=BF16, device=dev)
         _lib.gemm_bf16(h_full, self._prep["ffn0"].w, self._prep["ffn0"].b, mid, EPI_GELU_BF16, M=Lf)
+        # ffn.2's leftover rows (1 120 of 22 880) as one round of 256 x 256 tiles x split-K 4 where the library has that strip for the
+        # shape (K >= 8192): it needs scratch for the partial tiles (63 MB at this shape; the allocator hands every block the same one)
+        nws = _splitk_ws_bytes(L, C, self.ffn_dim, dev)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws else None
         _lib.gemm_bf16(mid, self._prep["ffn2"].w, self._prep["ffn2"].b, x, EPI_GATE_RESID_F32, M=L,
-                       gate=tab[:, 5 * C:], gate_tid=tid)
+                       gate=tab[:, 5 * C:], gate_tid=tid, ws=ws)
 
     def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens=None):
         """Reference signature (model.py:219-259): x [B, L, C], e [B, L, 6, C] fp32 -> [B, L, C] fp32.
@@ -394,6 +398,22 @@ _zero_cache = {}
 
 
 _ncu = {}
+
+
+_ws_bytes = {}
+SPLITK_STRIP = False     # opt-in (bench.py --splitk-strip): ffn.2's leftover rows as one round of 256 x 256 tiles x split-K 4 (uv_gemm_bf16_nt_ws).
+# OFF by default: measured -0.35 ... -0.5 ms of a 251 ms step (round 6), and it ends the property every other schedule of the GEMM keeps - a row's
+# bits do not depend on which rows it is launched with - so the stacked CFG pair would no longer be bit-identical to two batch-1 forwards
+
+
+def _splitk_ws_bytes(M, N, K, dev):
+    if not SPLITK_STRIP:
+        return 0
+    key = (M, N, K, str(dev))
+    n = _ws_bytes.get(key)
+    if n is None:
+        n = _ws_bytes[key] = _lib.gemm_splitk_ws_bytes(M, N, K, dev)
+    return n
 
 
 def _ffn0_rows(L, n_cols, dev):
