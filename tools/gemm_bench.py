@@ -39,6 +39,7 @@ SHAPES = [
     ("q+k as ONE N=6144 launch", L2, 6144, 3072, EPI_BF16),       # measured 652-654 us against 2 x 327.7 us (shape 0): no gain
     ("q+k+v-sized N=9216 launch", L2, 9216, 3072, EPI_BF16),      # 960 us against 3 x 327.7 (-2.4 %; the V third would need the transposed epilogue)
     ("aligned ffn.0 shape, GELU", 22784, 14336, 3072, EPI_GELU_BF16),   # against shape 14 (plain bf16 epilogue): the GELU epilogue's surcharge
+    ("ranker q+k+v as ONE N=2304 launch", 16384, 2304, 768, EPI_BF16),  # round 6, against 3 x shape 16: 576 tiles (2.25 rounds) against 3 x 192 (3 x 0.75)
 ]
 
 
