@@ -332,6 +332,26 @@ def test_gemm_ffn2_strip_takes_splitk_with_a_workspace():
     assert not torch.equal(with_ws[m_main:], plain[m_main:]) and (d == 0).float().mean() >= 0.999 and float(d.max()) < 0.04
 
 
+def test_host_blocking_sync_policy_can_be_set_and_reset():
+    """uv_host_blocking_sync: hipDeviceScheduleBlockingSync for the current device and back to the runtime's default, while the device is in
+    use (bench.py toggles it between two generations of one process); results of a launch in between are unaffected."""
+    from univid_amd import parallel
+    from univid_amd._lib import EPI_BF16
+    a = torch.randn(256, 128, device=DEV).to(BF16)
+    w = torch.randn(64, 128, device=DEV).to(BF16)
+    ref = torch.zeros(256, 64, dtype=BF16, device=DEV)
+    L().gemm_bf16(a, w, None, ref, EPI_BF16)
+    for on in (True, False, True):
+        L().host_blocking_sync(on)
+        out = torch.zeros(256, 64, dtype=BF16, device=DEV)
+        L().gemm_bf16(a, w, None, out, EPI_BF16)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    parallel.host_policy(torch.device(DEV if ":" in DEV else DEV + ":0"))
+    L().host_blocking_sync(False)
+    parallel._blocking_set.clear()
+
+
 def test_gemm_rejects_bad_shapes():
     from univid_amd._lib import EPI_BF16, UnividHipError
     a = torch.zeros(8, 48, dtype=BF16, device=DEV)

