@@ -23,12 +23,36 @@ import os
 import sys
 import time
 
-# Host scheduling is decided BEFORE the HIP runtime loads (it reads its environment when `import torch` maps libamdhip64): with the runtime's
+# Host scheduling is decided BEFORE the HIP runtime loads (it reads its environment when the first HIP call initialises it): with the runtime's
 # default ("direct dispatch") a HIP-graph replay is submitted by a runtime thread that SPINS while launches are pending - 122-235 ms of CPU per
-# 251 ms step, one busy core per rank (round 5 / 6 measurements) - whatever hipDeviceScheduleBlockingSync says; with AMD_DIRECT_DISPATCH=0 the
+# 251 ms step, one busy core per rank (round 5 / 6 measurements), whatever hipDeviceScheduleBlockingSync says; with AMD_DIRECT_DISPATCH=0 the
 # runtime's command thread blocks instead, and together with uv_host_blocking_sync a whole generation costs 3.4 ms of CPU per step at the same
-# step time. `--host-sync default` leaves both alone. The N ranks torchrun starts run this same file, so each sets it for itself.
-if not any(a == "--host-sync=default" or (a == "--host-sync" and sys.argv[i + 1:i + 2] == ["default"]) for i, a in enumerate(sys.argv)):
+# step time. So the ranks of a multi-GPU job run under AMD_DIRECT_DISPATCH=0 (`--host-sync auto`, the default: N ranks must not spin N cores of
+# one host; `blocking` forces it at N = 1 too, `default` leaves the runtime alone). The single-GPU line keeps direct dispatch because HIP events
+# around an EAGER launch read 5 % long under the command thread (same box: the self-attention launch 2.857 -> 3.005 ms by events, 2.84 in the
+# rocprofv3 trace either way) and `roofline` is measured exactly so; its `pipeline_path.host_sync.rank_policy_child` runs one generation in a
+# child process under the ranks' policy, so the figure is in every line.
+def _host_sync_mode():
+    for i, a in enumerate(sys.argv):
+        if a.startswith("--host-sync="):
+            return a.split("=", 1)[1]
+        if a == "--host-sync" and i + 1 < len(sys.argv):
+            return sys.argv[i + 1]
+    return "auto"
+
+
+def _world_hint():
+    if "WORLD_SIZE" in os.environ:
+        return int(os.environ["WORLD_SIZE"])
+    for i, a in enumerate(sys.argv):
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+    return 1
+
+
+if _host_sync_mode() == "blocking" or (_host_sync_mode() == "auto" and (_world_hint() > 1 or "--host-probe" in sys.argv)):
     os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
 
 import torch
@@ -222,18 +246,11 @@ def default_shape_probe(model, device, cfg, steps=3):
             "finite": bool(torch.isfinite(lat).all().item())}
 
 
-def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=10, blocking=True):
-    """UniVid's OWN entry point on the metric's shape: CrossAttentionFusionPipeline.generate_video_with_bagel_context (reference
-    models/model_pipeline.py:2577-2655, what inference.py:311,377 calls) -> Wan22ContextWrapper.generate -> WanTI2V.t2v, with inference.py's
-    settings (:52-80: 50 steps, dynamic text weight cosine 1.3 -> 1.0 over int(50 * 0.4) = 20 forwards = the first 10 steps), a stub BAGEL
-    extractor returning [1, 128, 3584] tokens, the HIP ContextProjector, prompt embeddings passed in, decode=False. Timed: ONE whole
-    50-step generation (after a 2-step one that captures the graph), wall clock around the call. Beside it the same entry point with
-    native_text_weight=False: the reference's closures on every WanCrossAttention.forward and the DiT forward, executed on the model's
-    generic path (two batch-1 forwards per step, context K / V re-projected in every block, un-fused residual, no graph).
-    OUTSIDE the metric's timed region; the metric's own loop is WanTI2V.denoise's plain step, which this path equals once w = 1."""
+def _pipeline_probe_parts(model, device, cfg):
+    """What pipeline_path_probe and the host-policy child build: the WanTI2V around `model`, inference.py's config, a stub BAGEL extractor
+    returning [1, 128, 3584] tokens, the HIP ContextProjector, and the keyword arguments of the generation call."""
     import types
-    from univid_amd import _lib
-    from univid_amd.model_pipeline import ContextProjector, CrossAttentionConfig, CrossAttentionFusionPipeline
+    from univid_amd.model_pipeline import ContextProjector, CrossAttentionConfig
     from univid_amd.wan.textimage2video import TI2VConfig, WanTI2V
     g = torch.Generator(device=device).manual_seed(21)
     tokens = torch.randn(1, 128, 3584, device=device, generator=g).to(torch.bfloat16)
@@ -250,6 +267,63 @@ def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=
     emb = [torch.randn(77, cfg["text_dim"], device=device, generator=g) * 0.1]
     emb_n = [torch.randn(12, cfg["text_dim"], device=device, generator=g) * 0.1]
     kw = dict(guidance_scale=GUIDE, frames=49, size=(1280, 704), shift=SHIFT, decode=False, prompt_embeds=emb, negative_prompt_embeds=emb_n, noise=noise)
+    return pipe, ccfg, bagel, proj, kw, g
+
+
+def host_probe_main():
+    """`bench.py --host-probe` (a child of the N = 1 run, started before that run touches the GPU, with AMD_DIRECT_DISPATCH=0 in its environment): the
+    host policy the ranks of an N > 1 job run under - command-thread dispatch + hipDeviceScheduleBlockingSync - on the metric's model and shape through
+    UniVid's entry point: process CPU per step of one whole 12-step generation (after a 2-step one that captures the graph). Prints one JSON line."""
+    from univid_amd import _lib
+    from univid_amd.model_pipeline import CrossAttentionFusionPipeline
+    from univid_amd.wan.textimage2video import TI2VConfig
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    _lib.host_blocking_sync(True, device)
+    _lib.init()
+    cfg = {k: v for k, v in TI2VConfig.dit.items() if k not in ("model_type", "window_size", "qk_norm", "cross_attn_norm")}
+    model = build_model(cfg, device, seed=0)
+    pipe, ccfg, bagel, proj, kw, _ = _pipeline_probe_parts(model, device, cfg)
+    n = 12
+    with torch.no_grad():
+        fusion = CrossAttentionFusionPipeline(ccfg, wan_pipeline=pipe, bagel_extractor=bagel, context_projector=proj)
+        fusion.generate_video_with_bagel_context("a prompt", steps=2, **kw)
+        torch.cuda.synchronize()
+        cpu0, t0 = time.process_time(), time.perf_counter()
+        lat, _ = fusion.generate_video_with_bagel_context("a prompt", steps=n, **kw)
+        cpu1 = time.process_time()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(json.dumps({"policy": "AMD_DIRECT_DISPATCH=%s + hipDeviceScheduleBlockingSync (what bench.py's ranks run under at N > 1; univid_amd.parallel.RANK_ENV / host_policy)"
+                                % os.environ.get("AMD_DIRECT_DISPATCH"), "steps": n, "ms_per_step": round(dt / n * 1e3, 2),
+                      "host_cpu_ms_per_step": round((cpu1 - cpu0) / n * 1e3, 3), "graph": pipe._runner is not None, "finite": bool(torch.isfinite(lat).all().item())}), flush=True)
+
+
+def run_host_probe_child():
+    """Starts host_probe_main in a child process. Called BEFORE this process initialises the GPU (a fork + exec from a process that has is what the
+    pool forbids), exactly like the `--gpus N` launcher below."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-probe"], env=dict(os.environ, AMD_DIRECT_DISPATCH="0"),
+                           capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
+    except Exception as ex:      # a side measurement: never fails the bench
+        return {"error": repr(ex)[:300]}
+
+
+def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=10, blocking=True):
+    """UniVid's OWN entry point on the metric's shape: CrossAttentionFusionPipeline.generate_video_with_bagel_context (reference
+    models/model_pipeline.py:2577-2655, what inference.py:311,377 calls) -> Wan22ContextWrapper.generate -> WanTI2V.t2v, with inference.py's
+    settings (:52-80: 50 steps, dynamic text weight cosine 1.3 -> 1.0 over int(50 * 0.4) = 20 forwards = the first 10 steps), a stub BAGEL
+    extractor returning [1, 128, 3584] tokens, the HIP ContextProjector, prompt embeddings passed in, decode=False. Timed: ONE whole
+    50-step generation (after a 2-step one that captures the graph), wall clock around the call. Beside it the same entry point with
+    native_text_weight=False: the reference's closures on every WanCrossAttention.forward and the DiT forward, executed on the model's
+    generic path (two batch-1 forwards per step, context K / V re-projected in every block, un-fused residual, no graph).
+    OUTSIDE the metric's timed region; the metric's own loop is WanTI2V.denoise's plain step, which this path equals once w = 1."""
+    from univid_amd import _lib
+    from univid_amd.model_pipeline import CrossAttentionFusionPipeline
+    pipe, ccfg, bagel, proj, kw, g = _pipeline_probe_parts(model, device, cfg)
     res = {"entry": "CrossAttentionFusionPipeline.generate_video_with_bagel_context(prompt_embeds=, decode=False) -> Wan22ContextWrapper -> WanTI2V.t2v",
            "workload": f"the metric's latent {list(LATENT)}, L={L_TOKENS}; inference.py's schedule: cosine text weight 1.3 -> 1.0 over the first "
                        f"{int(SAMPLING_STEPS * 0.4)} forwards of {SAMPLING_STEPS} steps, first 128 context rows, all {cfg['num_layers']} blocks"}
@@ -281,10 +355,13 @@ def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=
                 _, spin = timed(fusion, closure_steps)
             finally:
                 _lib.host_blocking_sync(True, device)
-            res["host_sync"] = {"policy": "hipDeviceScheduleBlockingSync + AMD_DIRECT_DISPATCH=%s (bench.py --host-sync blocking, the default; univid_amd.parallel.host_policy / RANK_ENV)" % os.environ.get("AMD_DIRECT_DISPATCH"),
+            res["host_sync"] = {"policy": "hipDeviceScheduleBlockingSync, AMD_DIRECT_DISPATCH=%s (this process)" % os.environ.get("AMD_DIRECT_DISPATCH", "unset = direct dispatch"),
                                 "host_cpu_ms_per_step": res["native"]["host_cpu_ms_per_step"],
-                                "default_policy_host_cpu_ms_per_step": spin["host_cpu_ms_per_step"], "default_policy_ms_per_step": spin["ms_per_step"],
-                                "default_policy_steps": closure_steps}
+                                "schedule_auto_host_cpu_ms_per_step": spin["host_cpu_ms_per_step"], "schedule_auto_ms_per_step": spin["ms_per_step"],
+                                "schedule_auto_steps": closure_steps,
+                                "note": "process CPU (all threads) per step of a whole generation. schedule_auto = the same call after uv_host_blocking_sync(0) "
+                                        "(hipDeviceScheduleAuto: the waiting main thread spins too). rank_policy_child = the same entry point in a child process "
+                                        "under what the ranks of an N > 1 job run with (AMD_DIRECT_DISPATCH=0 + blocking sync)"}
         # i2v through the same entry point (inference.py:365-385: image=...): one 704x1280 frame encoded by the VAE (f16x3, random-init), its
         # latent frame held fixed through the loop (timestep 0 on its tokens, the {0, t} table of the graph runner); 50 steps, encode included
         try:
@@ -623,8 +700,11 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer DiT blocks (result is NOT the metric)")
     ap.add_argument("--splitk-strip", action="store_true", help="A/B: ffn.2's leftover rows as one round of 256x256 tiles x split-K 4 (uv_gemm_bf16_nt_ws) instead of "
                     "the 128x128 ring; opt-in because its rows are not bit-identical to the unsplit accumulation (DESIGN 9, round 6)")
-    ap.add_argument("--host-sync", choices=["blocking", "default"], default="blocking", help="host scheduling policy of this rank's device: blocking = "
-                    "hipDeviceScheduleBlockingSync (a waiting host thread sleeps; what one-rank-per-GPU launches want), default = the runtime's (spins)")
+    ap.add_argument("--host-sync", choices=["auto", "blocking", "default"], default="auto", help="host scheduling policy of a rank: auto = "
+                    "hipDeviceScheduleBlockingSync always, plus AMD_DIRECT_DISPATCH=0 for the ranks of an N > 1 job (see the top of this file); blocking = both, "
+                    "at N = 1 too; default = the runtime's own (a waiting thread spins)")
+    ap.add_argument("--host-probe", action="store_true", help="internal: one short generation through the pipeline path under the ranks' host policy; prints "
+                    "its host CPU per step (started as a child by the N = 1 run, before that run touches the GPU)")
     ap.add_argument("--kernel-times", action="store_true", help="HIP-event timing of every kernel class (adds ~1%% overhead)")
     ap.add_argument("--shape", choices=["A", "B"], default="A", help="A (default, the metric): 49-frame 704x1280 latent [48,13,44,80], "
                     "L = 11 440. B: the literal '49x90x160 latent' stress shape of BASELINE.json's target, [48,49,90,160], L = 176 400 "
@@ -653,6 +733,11 @@ def main():
     if os.environ.get("UV_BENCH_DRYRUN"):      # launcher plumbing check (tests/test_host_logic.py): no GPU is touched
         print(json.dumps({"dryrun": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus}), flush=True)
         return
+    if args.host_probe:
+        return host_probe_main()
+    # (before anything below touches the GPU:) the ranks' host policy measured in a child, for the pipeline_path sub-line of the N = 1 run
+    host_probe = run_host_probe_child() if (world == 1 and args.gpus == 1 and args.host_sync == "auto" and not args.no_pipeline_path and not args.layers
+                                            and args.shape == "A") else None
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: start one rank per GPU "
                          f"(`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`)")
@@ -675,7 +760,7 @@ def main():
     cfg = dict(TI2V_5B_CFG)
     if args.layers:
         cfg["num_layers"] = args.layers
-    if args.host_sync == "blocking":
+    if args.host_sync != "default":
         _lib.host_blocking_sync(True, device)      # before this rank's first synchronize: N ranks must not spin N cores of one host
     _lib.init()
     if args.splitk_strip:
@@ -749,7 +834,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         cpu2 = time.process_time()
-        mine = {"rank": rank, "ms_per_step": round(ev[0].elapsed_time(ev[1]) / args.steps, 3), "allgather_us": round(ev[1].elapsed_time(ev[2]) * 1e3, 1),
+        mine = {"rank": rank, "ms_per_step": round(ev[0].elapsed_time(ev[1]) / args.steps, 3), "allgather_us": round(ev[1].elapsed_time(ev[2]) * 1e3, 1) if world > 1 else None,
                 "host_cpu_ms_per_step_enqueue": round((cpu1 - cpu0) / args.steps * 1e3, 3),
                 "host_cpu_ms_per_step_incl_wait": round((cpu2 - cpu0) / args.steps * 1e3, 3)}
         per_rank = [mine]
@@ -833,7 +918,7 @@ def main():
             "launches_per_step": round((calls1 - calls0) / args.steps, 1),
             "graph": bool(use_graph),
             "per_rank": {"ms_per_step_min": min(r["ms_per_step"] for r in per_rank), "ms_per_step_max": max(r["ms_per_step"] for r in per_rank),
-                         "allgather_us_max": max(r["allgather_us"] for r in per_rank),
+                         "allgather_us_max": max(r["allgather_us"] for r in per_rank) if world > 1 else None,
                          "host_cpu_ms_per_step_incl_wait_max": max(r["host_cpu_ms_per_step_incl_wait"] for r in per_rank), "ranks": per_rank,
                          "note": "per rank, HIP events on its launch stream inside the timed region: its own K steps (GPU time), then the one all-gather "
                                  "(includes waiting for the slowest rank); host CPU = process time of the rank, enqueue only / up to the closing barrier"},
@@ -849,7 +934,9 @@ def main():
             runner = None
             torch.cuda.empty_cache()
             try:
-                out["pipeline_path"] = pipeline_path_probe(model, device, cfg, blocking=(args.host_sync == "blocking"))
+                out["pipeline_path"] = pipeline_path_probe(model, device, cfg, blocking=(args.host_sync != "default"))
+                if host_probe is not None:
+                    out["pipeline_path"].setdefault("host_sync", {})["rank_policy_child"] = host_probe
                 out["pipeline_path"]["vs_headline_ms_per_step"] = round(out["pipeline_path"]["ms_per_step"] / out["ms_per_step"], 4)
             except Exception as ex:      # a side measurement: never fails the bench
                 out["pipeline_path"] = {"error": repr(ex)[:300]}

@@ -2071,6 +2071,47 @@ def test_vae_workspace_arena_repeat_calls_allocate_nothing_on_the_device():
     assert torch.isfinite(v1).all() and torch.equal(v1, v2)
 
 
+def test_vae_out_of_memory_retry_releases_the_arena_and_gives_the_same_bits():
+    """WanVAE_._with_pass_length with the arena ON (round-5 advisor finding: only stubs exercised it): a decode that runs out of memory at
+    the configured pass length - simulated: the pass body raises torch.cuda.OutOfMemoryError from INSIDE the arena scope, after the
+    engine has filled the pool, exactly where a real allocation failure surfaces - is retried at half the length; the engine and the pool
+    of the failed pass are dropped once the handler has exited (the traceback no longer pins their blocks), so the memory the pool
+    reserved really returns to the device before the retry allocates, and the result has the bits of an undisturbed decode."""
+    import gc
+    from univid_amd.wan.vae2_2 import Wan2_2_VAE
+    vae = Wan2_2_VAE(c_dim=32, dec_dim=32, device=DEV, seed=3)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    z = torch.randn(48, 5, 6, 10, device=DEV, generator=g)
+    m = vae.model
+    with torch.no_grad():
+        ref = vae.decode([z])[0]
+        torch.cuda.synchronize()
+        pool0 = m._pool
+        assert pool0 is not None and m._engine is not None
+        orig, seen = m._decode, []
+
+        def failing(G, zz, scale):
+            seen.append(G)
+            if len(seen) == 1:
+                with m._arena():
+                    ballast = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)     # lives in the arena, referenced by this frame only
+                    raise torch.cuda.OutOfMemoryError("simulated: HIP out of memory")
+            assert m._engine is None and m._pool is None, "the failed pass's engine and pool must be gone before the retry"
+            return orig(G, zz, scale)
+        m._decode = failing
+        try:
+            del pool0
+            gc.collect()
+            r0 = torch.cuda.memory_reserved(DEV)
+            out = vae.decode([z])[0]
+        finally:
+            del m._decode
+        torch.cuda.synchronize()
+    assert seen == [4, 2], seen
+    assert torch.equal(out, ref)
+    assert m._pool is not None and torch.cuda.memory_reserved(DEV) <= r0 + (8 << 20), "the arena of the failed pass was not released"
+
+
 def test_vae_pass_length_does_not_change_the_result():
     """Decoder passes of several latent frames / encoder passes of several 4-frame chunks (WanVAE_.frames_per_pass) against the
     reference's one-at-a-time streaming (vae2_2.py:797-806, 824-835): every layer is time-causal with a 2-frame cache, so the values

@@ -3,7 +3,7 @@
 # usage: final_profiles.sh [quick]   (quick: tests, DiT profiles and the bench line only)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/pytest_gpu.log
+python -m pytest tests -m gpu -q --durations=8 > gpurun_out/pytest_gpu_full.log 2>&1; tail -14 gpurun_out/pytest_gpu_full.log > gpurun_out/pytest_gpu.log
 bash tools/collect_profiles.sh
 ( time python3 bench.py ) > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 if [ "$1" != "quick" ]; then
