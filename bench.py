@@ -744,11 +744,19 @@ def main():
     import torch.distributed as dist
     # host threads: the loop's host side is scalar sampler algebra; never let N ranks open N x 256-thread pools on one host
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(world, 1))))
+    # UV_BENCH_SHARE_GPU=1 (test hook, tests/test_gpu_parity.py: the multi-rank branch of this file on a 1-GPU box): every rank uses cuda:0 and the
+    # group runs on gloo - RCCL needs one device per rank. Never set by the driver; the line says so ("transport").
+    share_gpu = world > 1 and os.environ.get("UV_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     global LATENT, L_TOKENS
     if args.shape == "B":
@@ -929,7 +937,9 @@ def main():
         }
         if args.kernel_times:
             out["kernel_times"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in ktimes.items()}
-        out["rccl_ranks"] = world if world > 1 else 0
+        out["rccl_ranks"] = world if (world > 1 and not share_gpu) else 0
+        if share_gpu:
+            out["transport"] = "gloo, all ranks on cuda:0 (UV_BENCH_SHARE_GPU=1 test hook: NOT a multi-GPU measurement)"
         if world == 1 and not args.no_pipeline_path and args.shape == "A":
             runner = None
             torch.cuda.empty_cache()
