@@ -3176,6 +3176,13 @@ def test_siglip2_towers_vs_transformers_golden():
     v = sc.emb_imgs(frames, bs=64)
     assert torch.allclose(v.norm(dim=-1).cpu(), torch.ones(len(frames)), atol=1e-5)
     assert sc.rank_frames([], "q", 3) == ([], [])
+    # the text tower on its side stream beside the vision tower (the default) == one tower after the other, bit for bit, call after call
+    assert sc.overlap_towers
+    both = [sc.rank_frames(frames, "q", topk=4, bs=4) for _ in range(3)]
+    sc.overlap_towers = False
+    serial = sc.rank_frames(frames, "q", topk=4, bs=4)
+    sc.overlap_towers = True
+    assert all(b == serial for b in both) and serial == (idx, vals)
     sel = mmr_select(v, sc.emb_text("q"), 3)
     assert len(sel) == 3 and len(set(sel)) == 3
     with pytest.raises(NotImplementedError):
