@@ -305,7 +305,7 @@ def run_host_probe_child():
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-probe"], env=dict(os.environ, AMD_DIRECT_DISPATCH="0"),
-                           capture_output=True, text=True, timeout=600)
+                           capture_output=True, text=True, timeout=240)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         return json.loads(lines[-1]) if lines else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
     except Exception as ex:      # a side measurement: never fails the bench

@@ -31,6 +31,17 @@ static bool strip_takes_splitk(const GemmArgs& at, int epilogue, const GemmWs& w
     return tiles * 4 <= num_cus() && ws.bytes >= splitk_ws_bytes(at.M, at.N, 4) && ((uintptr_t)ws.p & 255) == 0;
 }
 
+// The rows of an [M, N] projection (N % 256 == 0) that the persistent kernel takes under tile_cfg 0: every whole 256-row tile - or, when the
+// tile count is just above a whole number of rounds (the partial round under 45 % full: *short_round), only the row tiles of the whole rounds.
+// ONE place: gemm_entry cuts its launches here and uv_gemm_splitk_ws_bytes sizes the strip's workspace from the same cut.
+static long persistent_rows(int M, int N, bool* short_round) {
+    const long tn = N / 256, tm_full = M / 256;
+    const long tiles = (long)((M + 255) / 256) * tn;
+    const long rounds = tiles / num_cus(), rest = tiles - rounds * num_cus();
+    *short_round = rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus();
+    return *short_round ? rounds * num_cus() / tn * 256 : tm_full * 256;
+}
+
 // Rows that fill whole rounds of 256x256 tiles go to the big-tile kernel; the leftover rows (which would otherwise cost a
 // whole extra round on a fraction of the CUs) run as 128x128 tiles. Same arithmetic per element either way.
 // m_main > 0 names the split point explicitly (a multiple of 256).
@@ -90,14 +101,12 @@ static int gemm_entry(const void* A, long lda, const void* W, long ldw, const vo
         // Large projections: 256x256 tiles on the PERSISTENT 8-wave ping-pong kernel (one workgroup per CU walking its tile
         // list). It takes whole tiles only; rows beyond the last multiple of 256 - and, when the tile count is just above a
         // whole number of rounds, the rows of that partial round - run as 128x128 tiles on the small-tile kernel.
-        const long tn = N / 256, tm_full = M / 256;
-        const long tiles = (long)((M + 255) / 256) * tn;
-        const long rounds = tiles / num_cus(), rest = tiles - rounds * num_cus();
-        long m_main = tm_full * 256;
-        if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) m_main = rounds * num_cus() / tn * 256;
+        const long tn = N / 256;
+        bool short_round = false;
+        const long m_main = persistent_rows(M, N, &short_round);
         // (also when the transposed output's leading dimension does not allow the persistent kernel's 16-byte stores)
         if (m_main / 256 * tn < 2L * num_cus() || (epilogue == UV_EPI_BF16_T && ldo % 8 != 0)) {      // under two rounds of work: the one-tile-per-workgroup launch
-            if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) return launch_m_split<F16>(a, epilogue, 7, s);
+            if (short_round) return launch_m_split<F16>(a, epilogue, 7, s);
             return launch_by_cfg<F16>(a, epilogue, 7, s);
         }
         return launch_m_split<F16>(a, epilogue, 17, s, m_main, ws);
@@ -136,11 +145,9 @@ extern "C" int uv_gemm_bf16_nt_ws(const void* A, long lda, const void* W, long l
 // largest strip tile_cfg 0 can cut from M rows is one round of 256x256 tiles less one row of tiles.
 extern "C" long uv_gemm_splitk_ws_bytes(int M, int N, int K) {
     if (M < 2048 || N < 1024 || N % 256 != 0 || K < 8192 || K % 512 != 0) return 0;
-    const long tn = N / 256, tm_full = M / 256;
-    const long tiles = (long)((M + 255) / 256) * tn;
-    const long rounds = tiles / num_cus(), rest = tiles - rounds * num_cus();
-    long m_main = tm_full * 256;
-    if (rounds >= 1 && rest > 0 && rest * 100 < 45 * num_cus()) m_main = rounds * num_cus() / tn * 256;
+    const long tn = N / 256;
+    bool short_round = false;
+    const long m_main = persistent_rows(M, N, &short_round);
     if (m_main / 256 * tn < 2L * num_cus() || m_main >= M) return 0;
     const long strip_tiles = ((M - m_main) + 255) / 256 * tn;
     return strip_tiles * 4 <= num_cus() ? splitk_ws_bytes((int)(M - m_main), N, 4) : 0;
