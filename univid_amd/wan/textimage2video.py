@@ -489,7 +489,9 @@ class WanTI2V:
             self._step_done()
         return latent
 
-    # ---- host pacing: a step counter the GPU writes into pinned host memory at the end of every step; the host reads it as plain memory
+    # ---- host pacing: a step counter the GPU writes into pinned host memory at the end of every step; the host reads it as plain memory.
+    # One counter pair per pipeline, written on the stream the loop runs on: a pipeline object serves ONE stream at a time (as the reference's
+    # single-threaded, default-stream loop does); two threads driving one WanTI2V on two streams would interleave its counter writes.
     def _step_done(self):
         if self._progress is None:
             with torch.inference_mode(False):      # normal tensors: written in place by later calls inside or outside inference mode
