@@ -23,15 +23,17 @@ import os
 import sys
 import time
 
-# Host scheduling is decided BEFORE the HIP runtime loads (it reads its environment when the first HIP call initialises it): with the runtime's
-# default ("direct dispatch") a HIP-graph replay is submitted by a runtime thread that SPINS while launches are pending - 122-235 ms of CPU per
-# 251 ms step, one busy core per rank (round 5 / 6 measurements), whatever hipDeviceScheduleBlockingSync says; with AMD_DIRECT_DISPATCH=0 the
-# runtime's command thread blocks instead, and together with uv_host_blocking_sync a whole generation costs 3.4 ms of CPU per step at the same
-# step time. So the ranks of a multi-GPU job run under AMD_DIRECT_DISPATCH=0 (`--host-sync auto`, the default: N ranks must not spin N cores of
-# one host; `blocking` forces it at N = 1 too, `default` leaves the runtime alone). The single-GPU line keeps direct dispatch because HIP events
-# around an EAGER launch read 5 % long under the command thread (same box: the self-attention launch 2.857 -> 3.005 ms by events, 2.84 in the
-# rocprofv3 trace either way) and `roofline` is measured exactly so; its `pipeline_path.host_sync.rank_policy_child` runs one generation in a
-# child process under the ranks' policy, so the figure is in every line.
+# Host scheduling is decided BEFORE the HIP runtime initialises (it reads its environment then). With the runtime's default ("direct dispatch") a
+# HIP-graph replay is submitted by a runtime thread that SPINS while launches are pending - 122-235 ms of CPU per 251 ms step, one busy core per
+# rank (round 5 / 6 measurements), whatever hipDeviceScheduleBlockingSync says; with AMD_DIRECT_DISPATCH=0 the runtime's command thread blocks
+# instead, and together with uv_host_blocking_sync a whole generation costs 3.4-5.4 ms of CPU per step at the same step time
+# (profiles/r06_host_policy.md). `--host-sync auto` (the default): hipDeviceScheduleBlockingSync for every rank, the runtime's own dispatch mode -
+# RCCL has never run under AMD_DIRECT_DISPATCH=0 here (no multi-GPU box in six rounds), and the first N > 1 run must not also be the first run of
+# a dispatch mode; on this pool's 256-thread hosts eight spinning runtime threads cost nothing. `--host-sync blocking` adds AMD_DIRECT_DISPATCH=0
+# (for hosts where the cores matter, once validated there); `default` leaves the runtime alone. Every N = 1 line carries the measurement of the
+# `blocking` policy from a child process (`pipeline_path.host_sync.rank_policy_child`); the parent keeps direct dispatch also because HIP events
+# around an EAGER launch read 5 % long under the command thread (2.857 -> 3.005 ms on the self-attention launch; 2.84 in the rocprofv3 trace
+# either way) and `roofline` is measured exactly so.
 def _host_sync_mode():
     for i, a in enumerate(sys.argv):
         if a.startswith("--host-sync="):
@@ -41,18 +43,7 @@ def _host_sync_mode():
     return "auto"
 
 
-def _world_hint():
-    if "WORLD_SIZE" in os.environ:
-        return int(os.environ["WORLD_SIZE"])
-    for i, a in enumerate(sys.argv):
-        if a.startswith("--gpus="):
-            return int(a.split("=", 1)[1])
-        if a == "--gpus" and i + 1 < len(sys.argv):
-            return int(sys.argv[i + 1])
-    return 1
-
-
-if _host_sync_mode() == "blocking" or (_host_sync_mode() == "auto" and (_world_hint() > 1 or "--host-probe" in sys.argv)):
+if _host_sync_mode() == "blocking" or "--host-probe" in sys.argv:
     os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
 
 import torch
@@ -294,7 +285,7 @@ def host_probe_main():
         cpu1 = time.process_time()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    print(json.dumps({"policy": "AMD_DIRECT_DISPATCH=%s + hipDeviceScheduleBlockingSync (what bench.py's ranks run under at N > 1; univid_amd.parallel.RANK_ENV / host_policy)"
+    print(json.dumps({"policy": "AMD_DIRECT_DISPATCH=%s + hipDeviceScheduleBlockingSync (bench.py --host-sync blocking; univid_amd.parallel.RANK_ENV / host_policy)"
                                 % os.environ.get("AMD_DIRECT_DISPATCH"), "steps": n, "ms_per_step": round(dt / n * 1e3, 2),
                       "host_cpu_ms_per_step": round((cpu1 - cpu0) / n * 1e3, 3), "graph": pipe._runner is not None, "finite": bool(torch.isfinite(lat).all().item())}), flush=True)
 
@@ -361,7 +352,7 @@ def pipeline_path_probe(model, device, cfg, steps=SAMPLING_STEPS, closure_steps=
                                 "schedule_auto_steps": closure_steps,
                                 "note": "process CPU (all threads) per step of a whole generation. schedule_auto = the same call after uv_host_blocking_sync(0) "
                                         "(hipDeviceScheduleAuto: the waiting main thread spins too). rank_policy_child = the same entry point in a child process "
-                                        "under what the ranks of an N > 1 job run with (AMD_DIRECT_DISPATCH=0 + blocking sync)"}
+                                        "under AMD_DIRECT_DISPATCH=0 + blocking sync (--host-sync blocking: the policy for hosts whose cores matter)"}
         # i2v through the same entry point (inference.py:365-385: image=...): one 704x1280 frame encoded by the VAE (f16x3, random-init), its
         # latent frame held fixed through the loop (timestep 0 on its tokens, the {0, t} table of the graph runner); 50 steps, encode included
         try:
@@ -710,8 +701,8 @@ def main():
     ap.add_argument("--splitk-strip", action="store_true", help="A/B: ffn.2's leftover rows as one round of 256x256 tiles x split-K 4 (uv_gemm_bf16_nt_ws) instead of "
                     "the 128x128 ring; opt-in because its rows are not bit-identical to the unsplit accumulation (DESIGN 9, round 6)")
     ap.add_argument("--host-sync", choices=["auto", "blocking", "default"], default="auto", help="host scheduling policy of a rank: auto = "
-                    "hipDeviceScheduleBlockingSync always, plus AMD_DIRECT_DISPATCH=0 for the ranks of an N > 1 job (see the top of this file); blocking = both, "
-                    "at N = 1 too; default = the runtime's own (a waiting thread spins)")
+                    "hipDeviceScheduleBlockingSync, the runtime's own dispatch mode; blocking = that plus AMD_DIRECT_DISPATCH=0 (3-5 ms of host CPU per step "
+                    "instead of 120+; see the top of this file); default = the runtime's own (a waiting thread spins)")
     ap.add_argument("--host-probe", action="store_true", help="internal: one short generation through the pipeline path under the ranks' host policy; prints "
                     "its host CPU per step (started as a child by the N = 1 run, before that run touches the GPU)")
     ap.add_argument("--kernel-times", action="store_true", help="HIP-event timing of every kernel class (adds ~1%% overhead)")

@@ -3395,7 +3395,7 @@ def test_pipeline_composes_native_text_encoder_projector_dit():
 def test_bench_multi_rank_branch_runs_with_two_ranks_sharing_the_gpu():
     """bench.py's N > 1 branch - the bare `--gpus N` launcher (a child torch.distributed.run started before the parent touches the GPU), one rank per
     process, the barrier-bracketed timed region, the all-gather of the final latents, the max-over-ranks time, the per-rank HIP-event split and
-    the ranks' host policy (AMD_DIRECT_DISPATCH=0 + blocking sync) - has never met a multi-GPU box in six rounds. Here it runs for real on this
+    the ranks' host policy (blocking sync; `--host-sync blocking` adds AMD_DIRECT_DISPATCH=0) - has never met a multi-GPU box in six rounds. Here it runs for real on this
     box's single GPU: two ranks on cuda:0 over gloo (UV_BENCH_SHARE_GPU=1, a test hook the line itself labels), 2 DiT blocks, 2 timed steps.
     Checks the contract of the ONE JSON line rank 0 prints; the numbers are not a measurement."""
     import json
@@ -3404,15 +3404,15 @@ def test_bench_multi_rank_branch_runs_with_two_ranks_sharing_the_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, UV_BENCH_SHARE_GPU="1")
     env.pop("AMD_DIRECT_DISPATCH", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "2", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "2", "--no-cpu-baseline",
+                        "--host-sync", "blocking"], env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-400:], r.stderr[-800:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["finite"] is True
     assert d["metric"] == "denoise_steps_per_sec" and d["value"] > 0 and abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-2 * d["value"]
     assert d["rccl_ranks"] == 0 and "UV_BENCH_SHARE_GPU" in d["transport"]
-    assert d["host_env"]["AMD_DIRECT_DISPATCH"] == "0" and d["host_sync"] == "auto"
+    assert d["host_env"]["AMD_DIRECT_DISPATCH"] == "0" and d["host_sync"] == "blocking"      # (auto leaves the dispatch mode alone)
     pr = d["per_rank"]
     assert [x["rank"] for x in pr["ranks"]] == [0, 1]
     assert all(x["ms_per_step"] > 0 and x["allgather_us"] is not None and x["allgather_us"] >= 0 for x in pr["ranks"])

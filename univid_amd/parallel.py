@@ -16,10 +16,12 @@ import torch.distributed as dist
 
 _blocking_set = set()
 
-# What a one-rank-per-GPU launcher exports BEFORE its ranks import torch (the HIP runtime reads its environment when it is loaded):
+# What a one-rank-per-GPU launcher MAY export before its ranks initialise HIP (the runtime reads its environment then), on hosts whose cores matter:
 #   AMD_DIRECT_DISPATCH=0        HIP-graph replays are submitted by the runtime's command thread, which blocks while launches are pending; under
-#                                the default (direct dispatch) a runtime thread spins instead - one busy core per rank (bench.py: 122 ms of CPU
-#                                per 251 ms step, against 3.4 ms with this and host_policy() below; same step time)
+#                                the default (direct dispatch) a runtime thread spins instead - one busy core per rank (bench.py: 123 ms of CPU
+#                                per 251 ms step, against 3.4-5.4 ms with this and host_policy() below; same step time; profiles/r06_host_policy.md).
+#                                Measured at N = 1 only: RCCL has never run under it here (no multi-GPU box), so bench.py's own N > 1 ranks keep
+#                                the runtime's dispatch mode unless started with --host-sync blocking.
 #   HSA_ENABLE_IPC_MODE_LEGACY=0 dmabuf IPC for RCCL on this pool's driver
 RANK_ENV = {"AMD_DIRECT_DISPATCH": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
 
